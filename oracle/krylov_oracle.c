@@ -1,0 +1,765 @@
+/*
+ * krylov_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A single-threaded CPU restatement, in plain C, of the implicit-Euler / GMRES
+ * path of mfdeakin/krylov.  It exists so that the HIP implementation can be
+ * checked against the reference's arithmetic; it is never part of the product
+ * path and must only be used by tests/, the smoke check and the CPU-baseline
+ * leg of the benchmark.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).  Arithmetic is written in the reference's operation
+ * order; build with -ffp-contract=off and without -ffast-math so that no
+ * multiply-add is fused (the reference is built as ISO C++17 for baseline
+ * x86-64, which has neither FMA contraction nor FMA instructions).
+ *
+ * Index spaces
+ *   padded : fields T,u,v are (cx+2) x (cy+2) row-major, j fastest; interior
+ *            cell (i,j) lives at ((i+1),(j+1))          (include/mesh.hpp:77-120)
+ *   cell   : the unknown numbering of ImplicitEuler::cell_idx
+ *            (include/time_disc.hpp:341-376), N = (cx+2)(cy+2)-4 unknowns.
+ *
+ * The reference operator is a dense N x N matrix whose rows hold at most five
+ * non-zeros.  The dense row sum of include/matrix.hpp:23-33 runs over columns
+ * in ascending order starting from +0.0; adding the products of exact zeros
+ * does not change a finite partial sum, so a CSR row sum with ascending column
+ * indices is bit-identical for finite inputs.  Both forms are provided here
+ * and the test-suite checks the claim.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static double orc_snan(void) {
+  /* std::numeric_limits<double>::signaling_NaN(), include/constants.hpp:18 */
+  union { uint64_t u; double d; } x;
+  x.u = 0x7ff4000000000000ULL;
+  return x.d;
+}
+
+/* ------------------------------------------------------------------------ */
+/* include/matrix.hpp                                                        */
+/* ------------------------------------------------------------------------ */
+
+/* dot(matrix&, const matrix&, const matrix&), include/matrix.hpp:8-21 */
+ORC_API void orc_dense_matmul(double *res, const double *lhs, const double *rhs,
+                              long n, long k, long m) {
+  for (long i = 0; i < n; i++) {
+    for (long j = 0; j < m; j++) {
+      double acc = 0.0;
+      for (long p = 0; p < k; p++) {
+        acc += lhs[i * k + p] * rhs[p * m + j];
+      }
+      res[i * m + j] = acc;
+    }
+  }
+}
+
+/* dot(vector&, const matrix&, const vector&), include/matrix.hpp:23-33 */
+ORC_API void orc_dense_matvec(double *res, const double *a, const double *x,
+                              long rows, long cols) {
+  for (long i = 0; i < rows; i++) {
+    double acc = 0.0;
+    for (long k = 0; k < cols; k++) {
+      acc += a[i * cols + k] * x[k];
+    }
+    res[i] = acc;
+  }
+}
+
+/* Sparse form of include/matrix.hpp:23-33: same ascending-column row sum,
+ * restricted to the stored entries. */
+ORC_API void orc_csr_matvec(double *res, const int64_t *rowptr,
+                            const int32_t *col, const double *val,
+                            const double *x, long n) {
+  for (long i = 0; i < n; i++) {
+    double acc = 0.0;
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) {
+      acc += val[p] * x[col[p]];
+    }
+    res[i] = acc;
+  }
+}
+
+/* dot(real&, const vector&, const vector&), include/matrix.hpp:35-44 */
+ORC_API double orc_dot(const double *lhs, const double *rhs, long n) {
+  double acc = 0.0;
+  for (long i = 0; i < n; i++) {
+    acc += lhs[i] * rhs[i];
+  }
+  return acc;
+}
+
+/* l2_norm, include/matrix.hpp:46-52 */
+ORC_API double orc_l2_norm(const double *v, long n) {
+  double l2 = 0.0;
+  for (long i = 0; i < n; i++) {
+    l2 += v[i] * v[i];
+  }
+  return sqrt(l2);
+}
+
+/* normalize, include/matrix.hpp:54-60 (true division, not a reciprocal) */
+ORC_API double orc_normalize(double *v, long n) {
+  const double l2 = orc_l2_norm(v, n);
+  for (long i = 0; i < n; i++) {
+    v[i] /= l2;
+  }
+  return l2;
+}
+
+/* ------------------------------------------------------------------------ */
+/* include/solver.hpp : LUSolver                                             */
+/* ------------------------------------------------------------------------ */
+
+/* LUSolver::lu_decomp, include/solver.hpp:58-96.  l and u are n x n. */
+ORC_API void orc_lu_decomp(const double *sys, double *l, double *u, long n) {
+  for (long p = 0; p < n * n; p++) {
+    l[p] = 0.0;
+    u[p] = 0.0;
+  }
+  for (long k = 0; k < n; k++) {
+    l[k * n + k] = 1.0;
+    u[k * n + k] = sys[k * n + k];
+    for (long j = 0; j < k; j++) {
+      u[k * n + k] -= l[k * n + j] * u[j * n + k];
+    }
+    u[k * n + k] /= l[k * n + k];
+    for (long j = k + 1; j < n; j++) {
+      u[k * n + j] = sys[k * n + j];
+      for (long i = 0; i < k; i++) {
+        u[k * n + j] -= l[k * n + i] * u[i * n + j];
+      }
+      u[k * n + j] /= l[k * n + k];
+    }
+    for (long j = k + 1; j < n; j++) {
+      l[j * n + k] = sys[j * n + k];
+      for (long i = 0; i < k; i++) {
+        l[j * n + k] -= l[j * n + i] * u[i * n + k];
+      }
+      l[j * n + k] /= u[k * n + k];
+    }
+  }
+}
+
+/* LUSolver::solve, include/solver.hpp:34-56.  work holds 2*n*n + n doubles. */
+ORC_API void orc_lu_solve(const double *sys, const double *rhs, double *x,
+                          long n, double *work) {
+  double *l = work, *u = work + n * n, *partial = work + 2 * n * n;
+  orc_lu_decomp(sys, l, u, n);
+  for (long i = 0; i < n; i++) {
+    partial[i] = rhs[i];
+    for (long j = 0; j < i; j++) {
+      partial[i] -= l[i * n + j] * partial[j];
+    }
+    partial[i] /= l[i * n + i];
+  }
+  for (long i = n - 1; i >= 0; i--) {
+    x[i] = partial[i];
+    for (long j = i + 1; j < n; j++) {
+      x[i] -= u[i * n + j] * x[j];
+    }
+    x[i] /= u[i * n + i];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* include/solver.hpp : SparseTriDiagSolver / TriDiagSolver                  */
+/* ------------------------------------------------------------------------ */
+
+/* SparseTriDiagSolver::solve, include/solver.hpp:246-273.
+ * diags is n x 3 (lower, diagonal, upper); u_diag holds n-1 doubles. */
+ORC_API void orc_sparse_tridiag_solve(const double *diags, const double *sol,
+                                      double *vars, double *u_diag, long n) {
+  vars[0] = sol[0] / diags[1];
+  if (n > 1) u_diag[0] = diags[2] / diags[1];
+  for (long i = 1; i < n; i++) {
+    const double diag = diags[i * 3 + 1] - u_diag[i - 1] * diags[i * 3 + 0];
+    vars[i] = (sol[i] - vars[i - 1] * diags[i * 3 + 0]) / diag;
+    if (i + 1 < n) {
+      u_diag[i] = diags[i * 3 + 2] / diag;
+    }
+  }
+  for (long i = n - 2; i >= 0; i--) {
+    vars[i] -= vars[i + 1] * u_diag[i];
+  }
+}
+
+/* TriDiagSolver::solve, include/solver.hpp:340-364 (dense n x n input). */
+ORC_API void orc_tridiag_solve(const double *sys, const double *sol,
+                               double *vars, double *u_diag, long n) {
+  vars[0] = sol[0] / sys[0];
+  if (n > 1) u_diag[0] = sys[1] / sys[0];
+  for (long i = 1; i < n; i++) {
+    const double diag = sys[i * n + i] - u_diag[i - 1] * sys[i * n + i - 1];
+    vars[i] = (sol[i] - vars[i - 1] * sys[i * n + i - 1]) / diag;
+    if (i + 1 < n) {
+      u_diag[i] = sys[i * n + i + 1] / diag;
+    }
+  }
+  for (long i = n - 2; i >= 0; i--) {
+    vars[i] -= vars[i + 1] * u_diag[i];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Linear operator handle used by the GMRES restatement                      */
+/* ------------------------------------------------------------------------ */
+
+typedef struct orc_op {
+  long n;
+  int kind; /* 0 dense, 1 csr */
+  const double *dense;
+  const int64_t *rowptr;
+  const int32_t *col;
+  const double *val;
+} orc_op;
+
+ORC_API orc_op *orc_op_dense(const double *a, long n) {
+  orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+  op->n = n;
+  op->kind = 0;
+  op->dense = a;
+  return op;
+}
+
+ORC_API orc_op *orc_op_csr(const int64_t *rowptr, const int32_t *col,
+                           const double *val, long n) {
+  orc_op *op = (orc_op *)calloc(1, sizeof(orc_op));
+  op->n = n;
+  op->kind = 1;
+  op->rowptr = rowptr;
+  op->col = col;
+  op->val = val;
+  return op;
+}
+
+ORC_API void orc_op_free(orc_op *op) { free(op); }
+
+ORC_API void orc_op_apply(const orc_op *op, double *y, const double *x) {
+  if (op->kind == 0) {
+    orc_dense_matvec(y, op->dense, x, op->n, op->n);
+  } else {
+    orc_csr_matvec(y, op->rowptr, op->col, op->val, x, op->n);
+  }
+}
+
+/* A(r,c) of the operator (0.0 where nothing is stored). */
+static double orc_op_entry(const orc_op *op, long r, long c) {
+  if (op->kind == 0) return op->dense[r * op->n + c];
+  for (int64_t p = op->rowptr[r]; p < op->rowptr[r + 1]; p++) {
+    if (op->col[p] == c) return op->val[p];
+  }
+  return 0.0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* include/solver.hpp : GMRESSolver<m> / GMRESTDPSolver<m>                   */
+/* ------------------------------------------------------------------------ */
+
+typedef struct orc_gmres {
+  long n;
+  int m;
+  int tdp;        /* 0: GMRESSolver, 1: GMRESTDPSolver */
+  int fixed_tdp;  /* opt-in: apply M^-1 to the combination (not in the reference) */
+  int nvec;       /* subspace.size() */
+  double *V;      /* (m+1) x n basis, row k = subspace[k] */
+  double *H;      /* (m+1) x m row-major */
+  double *vars;   /* Solver::vars, include/solver.hpp:14-19 */
+  double *next;   /* work vector of add_arnoldi */
+  double *lu_work;
+  double *sys, *rhs, *y;
+  double *tdiags, *td_vars, *td_udiag;
+} orc_gmres;
+
+ORC_API orc_gmres *orc_gmres_create(long n, int m, int tdp) {
+  orc_gmres *g = (orc_gmres *)calloc(1, sizeof(orc_gmres));
+  g->n = n;
+  g->m = m;
+  g->tdp = tdp;
+  g->V = (double *)malloc(sizeof(double) * (size_t)(m + 1) * (size_t)n);
+  g->H = (double *)calloc((size_t)(m + 1) * m, sizeof(double));
+  g->vars = (double *)malloc(sizeof(double) * (size_t)n);
+  g->next = (double *)malloc(sizeof(double) * (size_t)n);
+  g->lu_work = (double *)malloc(sizeof(double) * (size_t)(2 * m * m + m));
+  g->sys = (double *)malloc(sizeof(double) * (size_t)m * m);
+  g->rhs = (double *)malloc(sizeof(double) * (size_t)m);
+  g->y = (double *)malloc(sizeof(double) * (size_t)m);
+  for (long i = 0; i < n; i++) g->vars[i] = orc_snan(); /* solver.hpp:16-18 */
+  if (tdp) {
+    g->tdiags = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    g->td_vars = (double *)malloc(sizeof(double) * (size_t)n);
+    g->td_udiag = (double *)malloc(sizeof(double) * (size_t)n);
+  }
+  return g;
+}
+
+ORC_API void orc_gmres_free(orc_gmres *g) {
+  if (!g) return;
+  free(g->V); free(g->H); free(g->vars); free(g->next); free(g->lu_work);
+  free(g->sys); free(g->rhs); free(g->y);
+  free(g->tdiags); free(g->td_vars); free(g->td_udiag);
+  free(g);
+}
+
+ORC_API void orc_gmres_set_fixed_preconditioning(orc_gmres *g, int on) {
+  g->fixed_tdp = on;
+}
+
+/* GMRESSolver::initial_subspace, include/solver.hpp:168-174 */
+ORC_API double orc_gmres_initial_subspace(orc_gmres *g, const double *sol) {
+  memcpy(g->V, sol, sizeof(double) * (size_t)g->n);
+  const double beta = orc_normalize(g->V, g->n);
+  g->nvec = 1;
+  return beta;
+}
+
+/* GMRESTDPSolver::assemble_preconditioner, include/solver.hpp:295-314 */
+ORC_API void orc_gmres_assemble_preconditioner(orc_gmres *g, const orc_op *op) {
+  const long n = g->n;
+  double *t = g->tdiags;
+  t[0] = orc_snan();
+  t[1] = orc_op_entry(op, 0, 0);
+  t[2] = orc_op_entry(op, 0, 1);
+  for (long i = 1; i < n - 1; i++) {
+    t[i * 3 + 0] = orc_op_entry(op, i, i - 1);
+    t[i * 3 + 1] = orc_op_entry(op, i, i);
+    t[i * 3 + 2] = orc_op_entry(op, i, i + 1);
+  }
+  t[(n - 1) * 3 + 0] = orc_op_entry(op, n - 1, n - 2);
+  t[(n - 1) * 3 + 1] = orc_op_entry(op, n - 1, n - 1);
+  t[(n - 1) * 3 + 2] = orc_snan();
+}
+
+/* GMRESSolver::gram_schmidt, include/solver.hpp:196-211 (modified G-S, the
+ * dot is taken with the already-updated vector; `next -= h * v` is a
+ * multiply followed by a subtract). */
+static void orc_gram_schmidt(orc_gmres *g, double *next) {
+  const long n = g->n;
+  const int m = g->m;
+  const int j = g->nvec - 1;
+  for (int i = 0; i <= j; i++) {
+    const double *v = g->V + (size_t)i * n;
+    const double h = orc_dot(next, v, n);
+    g->H[i * m + j] = h;
+    for (long k = 0; k < n; k++) {
+      next[k] -= h * v[k];
+    }
+  }
+  g->H[(j + 1) * m + j] = orc_normalize(next, n);
+}
+
+/* GMRESSolver::add_arnoldi (include/solver.hpp:185-194) and the
+ * preconditioned override GMRESTDPSolver::add_arnoldi (:316-328). */
+ORC_API double orc_gmres_add_arnoldi(orc_gmres *g, const orc_op *op) {
+  const long n = g->n;
+  const int j = g->nvec - 1;
+  const double *prev = g->V + (size_t)j * n;
+  if (g->tdp) {
+    orc_sparse_tridiag_solve(g->tdiags, prev, g->td_vars, g->td_udiag, n);
+    orc_op_apply(op, g->next, g->td_vars);
+  } else {
+    orc_op_apply(op, g->next, prev);
+  }
+  orc_gram_schmidt(g, g->next);
+  memcpy(g->V + (size_t)(j + 1) * n, g->next, sizeof(double) * (size_t)n);
+  g->nvec++;
+  return g->H[(j + 1) * g->m + j];
+}
+
+/* GMRESSolver::solve (include/solver.hpp:124-161); GMRESTDPSolver::solve
+ * (:290-293) first rebuilds the tridiagonal preconditioner.  The returned
+ * vector is the plain combination of the basis vectors: for the
+ * preconditioned solver the reference does not apply M^-1 to it. */
+ORC_API const double *orc_gmres_solve(orc_gmres *g, const orc_op *op,
+                                      const double *sol) {
+  const long n = g->n;
+  const int m = g->m;
+  if (g->tdp) orc_gmres_assemble_preconditioner(g, op);
+  const double beta = orc_gmres_initial_subspace(g, sol);
+  for (int p = 0; p < (m + 1) * m; p++) g->H[p] = 0.0;
+  for (int i = 0; i < m; i++) {
+    orc_gmres_add_arnoldi(g, op);
+  }
+  /* sys = transpose(H) * H via the generic triple loop (solver.hpp:144-145) */
+  for (int i = 0; i < m; i++) {
+    for (int jj = 0; jj < m; jj++) {
+      double acc = 0.0;
+      for (int k = 0; k < m + 1; k++) {
+        acc += g->H[k * m + i] * g->H[k * m + jj];
+      }
+      g->sys[i * m + jj] = acc;
+    }
+  }
+  for (int i = 0; i < m; i++) {
+    g->rhs[i] = beta * g->H[0 * m + i];
+  }
+  orc_lu_solve(g->sys, g->rhs, g->y, m, g->lu_work);
+  for (long k = 0; k < n; k++) g->vars[k] = 0.0;
+  for (int i = 0; i < m; i++) {
+    const double *dim = g->V + (size_t)i * n;
+    const double s = g->y[i];
+    for (long k = 0; k < n; k++) {
+      g->vars[k] += s * dim[k];
+    }
+  }
+  if (g->tdp && g->fixed_tdp) {
+    /* Opt-in repair that is NOT in the reference: x = M^-1 u. */
+    orc_sparse_tridiag_solve(g->tdiags, g->vars, g->td_vars, g->td_udiag, n);
+    memcpy(g->vars, g->td_vars, sizeof(double) * (size_t)n);
+  }
+  return g->vars;
+}
+
+ORC_API const double *orc_gmres_subspace_vector(const orc_gmres *g, int i) {
+  return g->V + (size_t)i * g->n;
+}
+ORC_API double orc_gmres_hessenberg(const orc_gmres *g, int i, int j) {
+  return g->H[i * g->m + j];
+}
+ORC_API const double *orc_gmres_hessenberg_data(const orc_gmres *g) { return g->H; }
+ORC_API const double *orc_gmres_prev_result(const orc_gmres *g) { return g->vars; }
+ORC_API const double *orc_gmres_tdiags(const orc_gmres *g) { return g->tdiags; }
+ORC_API const double *orc_gmres_reduced_solution(const orc_gmres *g) { return g->y; }
+
+/* ------------------------------------------------------------------------ */
+/* include/mesh.hpp, include/space_disc.hpp, include/boundary_conds.hpp,     */
+/* include/time_disc.hpp                                                     */
+/* ------------------------------------------------------------------------ */
+
+enum { ORC_FIELD_T = 0, ORC_FIELD_U = 1, ORC_FIELD_V = 2 };
+enum { ORC_SIDE_BOTTOM = 0, ORC_SIDE_TOP = 1, ORC_SIDE_LEFT = 2, ORC_SIDE_RIGHT = 3 };
+
+typedef struct orc_ie {
+  int cx, cy;
+  double min_x, max_x, min_y, max_y, dx, dy;
+  double diffusion, reynolds, prandtl, eckert, inv_rp;
+  double time;
+  double *fld[3];          /* padded (cx+2) x (cy+2) */
+  double weight[3][4];     /* BoundaryCondition::weight_ per field, side */
+  double *bcval[3][4];     /* bc(x,y,t) sampled at the boundary-cell coords */
+  long n;
+  int64_t *rowptr;
+  int32_t *col;
+  double *val;
+  double *sol_vec;
+  orc_op *op;
+  orc_gmres *solver;
+} orc_ie;
+
+#define P_(s) ((s)->cy + 2)
+#define AT(s, f, i, j) ((s)->fld[f][((i) + 1) * P_(s) + ((j) + 1)])
+
+/* Mesh coordinate helpers, include/mesh.hpp:20-42 */
+ORC_API double orc_left_x(const orc_ie *s, int i) { return s->min_x + i * s->dx; }
+ORC_API double orc_right_x(const orc_ie *s, int i) { return s->min_x + (i + 1) * s->dx; }
+ORC_API double orc_bottom_y(const orc_ie *s, int j) { return s->min_y + j * s->dy; }
+ORC_API double orc_top_y(const orc_ie *s, int j) { return s->min_y + (j + 1) * s->dy; }
+ORC_API double orc_median_x(const orc_ie *s, int i) { return s->min_x + s->dx / 2 + i * s->dx; }
+ORC_API double orc_median_y(const orc_ie *s, int j) { return s->min_y + s->dy / 2 + j * s->dy; }
+
+/* ImplicitEuler::cell_idx, include/time_disc.hpp:341-376 */
+ORC_API long orc_cell_idx(const orc_ie *s, int i, int j) {
+  const int gc = 1;
+  if (i == -gc) {
+    return j;
+  } else if (i == s->cx) {
+    return s->cy + i * (s->cy + 2 * gc) + j;
+  } else {
+    return s->cy + i * (s->cy + 2 * gc) + gc + j;
+  }
+}
+
+/* SecondOrderCentered stencil coefficients, include/space_disc.hpp:83-113 */
+static double Dx_p1(const orc_ie *s, int i, int j) {
+  return (AT(s, 1, i + 1, j) / 2.0 - s->diffusion * s->inv_rp / s->dx) / s->dx;
+}
+static double Dx_0(const orc_ie *s) {
+  return 2.0 * s->diffusion * s->inv_rp / (s->dx * s->dx);
+}
+static double Dx_m1(const orc_ie *s, int i, int j) {
+  return (-AT(s, 1, i - 1, j) / 2.0 - s->diffusion * s->inv_rp / s->dx) / s->dx;
+}
+static double Dy_p1(const orc_ie *s, int i, int j) {
+  return (AT(s, 2, i, j + 1) / 2.0 - s->diffusion * s->inv_rp / s->dy) / s->dy;
+}
+static double Dy_0(const orc_ie *s) {
+  return 2.0 * s->diffusion * s->inv_rp / (s->dy * s->dy);
+}
+static double Dy_m1(const orc_ie *s, int i, int j) {
+  return (-AT(s, 2, i, j - 1) / 2.0 - s->diffusion * s->inv_rp / s->dy) / s->dy;
+}
+
+/* Face fluxes, include/space_disc.hpp:116-141 */
+static double uT_x_flux(const orc_ie *s, int i, int j) {
+  return (AT(s, 0, i, j) * AT(s, 1, i, j) + AT(s, 0, i + 1, j) * AT(s, 1, i + 1, j)) / 2.0;
+}
+static double vT_y_flux(const orc_ie *s, int i, int j) {
+  return (AT(s, 0, i, j) * AT(s, 2, i, j) + AT(s, 0, i, j + 1) * AT(s, 2, i, j + 1)) / 2.0;
+}
+static double dx_flux(const orc_ie *s, int i, int j) {
+  return (AT(s, 0, i + 1, j) - AT(s, 0, i, j)) / s->dx;
+}
+static double dy_flux(const orc_ie *s, int i, int j) {
+  return (AT(s, 0, i, j + 1) - AT(s, 0, i, j)) / s->dy;
+}
+
+/* EnergyAssembly::lapl_T_flux_integral, include/space_disc.hpp:33-44 */
+static double lapl_T_flux_integral(const orc_ie *s, int i, int j) {
+  const double x2_deriv = (dx_flux(s, i, j) - dx_flux(s, i - 1, j)) / s->dx;
+  const double y2_deriv = (dy_flux(s, i, j) - dy_flux(s, i, j - 1)) / s->dy;
+  return (x2_deriv + y2_deriv) * s->inv_rp;
+}
+
+/* EnergyAssembly::flux_integral, include/space_disc.hpp:19-31 */
+ORC_API double orc_flux_integral(const orc_ie *s, int i, int j) {
+  const double x_deriv = (uT_x_flux(s, i, j) - uT_x_flux(s, i - 1, j)) / s->dx;
+  const double y_deriv = (vT_y_flux(s, i, j) - vT_y_flux(s, i, j - 1)) / s->dy;
+  return (-x_deriv - y_deriv) + s->diffusion * lapl_T_flux_integral(s, i, j);
+}
+
+/* SecondOrderCentered::source_fd and the four centred differences,
+ * include/space_disc.hpp:145-179 */
+ORC_API double orc_source_fd(const orc_ie *s, int i, int j) {
+  const double u_dx = (AT(s, 1, i + 1, j) - AT(s, 1, i - 1, j)) / (2.0 * s->dx);
+  const double v_dy = (AT(s, 2, i, j + 1) - AT(s, 2, i, j - 1)) / (2.0 * s->dy);
+  const double u_dy = (AT(s, 1, i, j + 1) - AT(s, 1, i, j - 1)) / (2.0 * s->dy);
+  const double v_dx = (AT(s, 2, i + 1, j) - AT(s, 2, i - 1, j)) / (2.0 * s->dx);
+  const double cross_term = u_dy + v_dx;
+  return s->eckert / s->reynolds *
+         (2.0 * (u_dx * u_dx + v_dy * v_dy) + cross_term * cross_term);
+}
+
+/* BoundaryCondition::ghost_cell, include/boundary_conds.hpp:62-66 */
+ORC_API double orc_ghost_cell(double bndry_val, double bc, double size, double weight) {
+  return (2.0 * bc - bndry_val) * weight + (size * bc + bndry_val) * (1.0 - weight);
+}
+
+/* TimeDisc::apply_bcs (include/time_disc.hpp:146-163) with the view wiring of
+ * the TimeDisc constructor (:51-134):
+ *  - bottom/top conditions use size = dy, left/right use size = dx;
+ *  - every LEFT condition reads the RIGHT boundary column (:66-67, :93-94,
+ *    :121-122), which is reproduced here on purpose.
+ * All conditions read interior cells and write ghost cells only, so the call
+ * order of the reference has no effect on the result. */
+ORC_API void orc_ie_apply_bcs(orc_ie *s) {
+  const int cx = s->cx, cy = s->cy;
+  for (int f = 0; f < 3; f++) {
+    for (int j = 0; j < cy; j++) {
+      AT(s, f, -1, j) = orc_ghost_cell(AT(s, f, cx - 1, j), s->bcval[f][ORC_SIDE_LEFT][j],
+                                       s->dx, s->weight[f][ORC_SIDE_LEFT]);
+      AT(s, f, cx, j) = orc_ghost_cell(AT(s, f, cx - 1, j), s->bcval[f][ORC_SIDE_RIGHT][j],
+                                       s->dx, s->weight[f][ORC_SIDE_RIGHT]);
+    }
+    for (int i = 0; i < cx; i++) {
+      AT(s, f, i, cy) = orc_ghost_cell(AT(s, f, i, cy - 1), s->bcval[f][ORC_SIDE_TOP][i],
+                                       s->dy, s->weight[f][ORC_SIDE_TOP]);
+      AT(s, f, i, -1) = orc_ghost_cell(AT(s, f, i, 0), s->bcval[f][ORC_SIDE_BOTTOM][i],
+                                       s->dy, s->weight[f][ORC_SIDE_BOTTOM]);
+    }
+  }
+}
+
+/* position of A(r,c) in the CSR arrays (it must exist) */
+static int64_t orc_pos(const orc_ie *s, long r, long c) {
+  for (int64_t p = s->rowptr[r]; p < s->rowptr[r + 1]; p++) {
+    if (s->col[p] == c) return p;
+  }
+  return -1;
+}
+
+/* Sparsity pattern of the ImplicitEuler system in cell_idx numbering: the
+ * entries written by the constructor (include/time_disc.hpp:249-274) and by
+ * assemble_system (:294-337), columns ascending inside each row. */
+static void orc_ie_build_pattern(orc_ie *s) {
+  const int cx = s->cx, cy = s->cy;
+  const long n = s->n;
+  s->rowptr = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+  int64_t nnz = 5LL * cx * cy + 2LL * (2 * cx + 2 * cy);
+  s->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)nnz);
+  s->val = (double *)calloc((size_t)nnz, sizeof(double));
+  int64_t p = 0;
+  long r = 0;
+  for (int j = 0; j < cy; j++) { /* left ghost column */
+    s->rowptr[r++] = p;
+    s->col[p++] = (int32_t)orc_cell_idx(s, -1, j);
+    s->col[p++] = (int32_t)orc_cell_idx(s, 0, j);
+  }
+  for (int i = 0; i < cx; i++) {
+    s->rowptr[r++] = p; /* bottom ghost */
+    s->col[p++] = (int32_t)orc_cell_idx(s, i, -1);
+    s->col[p++] = (int32_t)orc_cell_idx(s, i, 0);
+    for (int j = 0; j < cy; j++) {
+      s->rowptr[r++] = p;
+      s->col[p++] = (int32_t)orc_cell_idx(s, i - 1, j);
+      s->col[p++] = (int32_t)orc_cell_idx(s, i, j - 1);
+      s->col[p++] = (int32_t)orc_cell_idx(s, i, j);
+      s->col[p++] = (int32_t)orc_cell_idx(s, i, j + 1);
+      s->col[p++] = (int32_t)orc_cell_idx(s, i + 1, j);
+    }
+    s->rowptr[r++] = p; /* top ghost */
+    s->col[p++] = (int32_t)orc_cell_idx(s, i, cy - 1);
+    s->col[p++] = (int32_t)orc_cell_idx(s, i, cy);
+  }
+  for (int j = 0; j < cy; j++) { /* right ghost column */
+    s->rowptr[r++] = p;
+    s->col[p++] = (int32_t)orc_cell_idx(s, cx - 1, j);
+    s->col[p++] = (int32_t)orc_cell_idx(s, cx, j);
+  }
+  s->rowptr[r] = p;
+}
+
+/* Mesh constructor geometry, src/mesh.cpp:8-21.  Fields are given already
+ * sampled at the cell medians (src/mesh.cpp:60-67); ghosts and corners start
+ * as signalling NaN (src/mesh.cpp:34-51). */
+ORC_API orc_ie *orc_ie_create(double c1x, double c1y, double c2x, double c2y,
+                              int cx, int cy, const double *T0, const double *u0,
+                              const double *v0, double diffusion, double reynolds,
+                              double prandtl, double eckert, const int *bc_is_dirichlet,
+                              int m, int tdp) {
+  orc_ie *s = (orc_ie *)calloc(1, sizeof(orc_ie));
+  s->cx = cx;
+  s->cy = cy;
+  s->min_x = c1x < c2x ? c1x : c2x;
+  s->max_x = c1x < c2x ? c2x : c1x;
+  s->min_y = c1y < c2y ? c1y : c2y;
+  s->max_y = c1y < c2y ? c2y : c1y;
+  s->dx = (s->max_x - s->min_x) / (double)cx;
+  s->dy = (s->max_y - s->min_y) / (double)cy;
+  s->diffusion = diffusion;
+  s->reynolds = reynolds;
+  s->prandtl = prandtl;
+  s->eckert = eckert;
+  s->inv_rp = 1.0 / (reynolds * prandtl); /* space_disc.hpp:61 */
+  s->time = 0.0;
+  const size_t np = (size_t)(cx + 2) * (cy + 2);
+  const double *src[3] = {T0, u0, v0};
+  for (int f = 0; f < 3; f++) {
+    s->fld[f] = (double *)malloc(sizeof(double) * np);
+    for (size_t k = 0; k < np; k++) s->fld[f][k] = orc_snan();
+    for (int i = 0; i < cx; i++)
+      for (int j = 0; j < cy; j++) AT(s, f, i, j) = src[f][(size_t)i * cy + j];
+    for (int side = 0; side < 4; side++) {
+      /* weight_ = 1 for Dirichlet, 0 for Neumann, boundary_conds.hpp:50 */
+      s->weight[f][side] = bc_is_dirichlet[f * 4 + side] ? 1.0 : 0.0;
+      const int len = (side == ORC_SIDE_BOTTOM || side == ORC_SIDE_TOP) ? cx : cy;
+      s->bcval[f][side] = (double *)calloc((size_t)len, sizeof(double));
+    }
+  }
+  s->n = (long)(cx + 2) * (cy + 2) - 4; /* num_eqns, time_disc.hpp:179-188 */
+  orc_ie_build_pattern(s);
+  s->sol_vec = (double *)calloc((size_t)s->n, sizeof(double));
+  s->op = orc_op_csr(s->rowptr, s->col, s->val, s->n);
+  s->solver = m > 0 ? orc_gmres_create(s->n, m, tdp) : 0;
+  return s;
+}
+
+ORC_API void orc_ie_free(orc_ie *s) {
+  if (!s) return;
+  for (int f = 0; f < 3; f++) {
+    free(s->fld[f]);
+    for (int side = 0; side < 4; side++) free(s->bcval[f][side]);
+  }
+  free(s->rowptr); free(s->col); free(s->val); free(s->sol_vec);
+  orc_op_free(s->op);
+  orc_gmres_free(s->solver);
+  free(s);
+}
+
+/* Values of bc(x, y, t) at the boundary-cell coordinates of one side, as the
+ * host evaluates them before every apply_bcs (the coordinates are those of
+ * include/time_disc.hpp:55-76). */
+ORC_API void orc_ie_set_bc_values(orc_ie *s, int field, int side, const double *vals) {
+  const int len = (side == ORC_SIDE_BOTTOM || side == ORC_SIDE_TOP) ? s->cx : s->cy;
+  memcpy(s->bcval[field][side], vals, sizeof(double) * (size_t)len);
+}
+
+/* Second half of the ImplicitEuler constructor, include/time_disc.hpp:246-274:
+ * ghost fill at t = 0, then the four off-diagonal bands, which are never
+ * refreshed afterwards. */
+ORC_API void orc_ie_init_offdiag(orc_ie *s) {
+  orc_ie_apply_bcs(s);
+  for (int i = 0; i < s->cx; i++) {
+    for (int j = 0; j < s->cy; j++) {
+      const long cur = orc_cell_idx(s, i, j);
+      s->val[orc_pos(s, cur, orc_cell_idx(s, i, j - 1))] = Dy_m1(s, i, j);
+      s->val[orc_pos(s, cur, orc_cell_idx(s, i, j + 1))] = Dy_p1(s, i, j);
+      s->val[orc_pos(s, cur, orc_cell_idx(s, i - 1, j))] = Dx_m1(s, i, j);
+      s->val[orc_pos(s, cur, orc_cell_idx(s, i + 1, j))] = Dx_p1(s, i, j);
+    }
+  }
+}
+
+/* ImplicitEuler::assemble_system, include/time_disc.hpp:291-339.  The right
+ * ghost rows take the LEFT condition's implicit_euler_term (:335-336). */
+ORC_API void orc_ie_assemble_system(orc_ie *s, double dt) {
+  const int cx = s->cx, cy = s->cy;
+  orc_ie_apply_bcs(s);
+  for (int i = 0; i < cx; i++) {
+    for (int j = 0; j < cy; j++) {
+      const long cur = orc_cell_idx(s, i, j);
+      s->val[orc_pos(s, cur, cur)] = Dx_0(s) + Dy_0(s) + 1.0 / dt;
+      s->sol_vec[cur] = orc_flux_integral(s, i, j) + orc_source_fd(s, i, j);
+    }
+  }
+  /* implicit_euler_term() = 2 w - 1, boundary_conds.hpp:77-81 */
+  const double term_top = 2.0 * s->weight[0][ORC_SIDE_TOP] - 1.0;
+  const double term_bottom = 2.0 * s->weight[0][ORC_SIDE_BOTTOM] - 1.0;
+  const double term_left = 2.0 * s->weight[0][ORC_SIDE_LEFT] - 1.0;
+  for (int i = 0; i < cx; i++) {
+    const long top = orc_cell_idx(s, i, cy);
+    s->sol_vec[top] = 0.0;
+    s->val[orc_pos(s, top, orc_cell_idx(s, i, cy - 1))] = 1.0;
+    s->val[orc_pos(s, top, top)] = term_top;
+    const long bot = orc_cell_idx(s, i, -1);
+    s->sol_vec[bot] = 0.0;
+    s->val[orc_pos(s, bot, orc_cell_idx(s, i, 0))] = 1.0;
+    s->val[orc_pos(s, bot, bot)] = term_bottom;
+  }
+  for (int j = 0; j < cy; j++) {
+    const long left = orc_cell_idx(s, -1, j);
+    s->sol_vec[left] = 0.0;
+    s->val[orc_pos(s, left, orc_cell_idx(s, 0, j))] = 1.0;
+    s->val[orc_pos(s, left, left)] = term_left;
+    const long right = orc_cell_idx(s, cx, j);
+    s->sol_vec[right] = 0.0;
+    s->val[orc_pos(s, right, orc_cell_idx(s, cx - 1, j))] = 1.0;
+    s->val[orc_pos(s, right, right)] = term_left;
+  }
+}
+
+/* ImplicitEuler::timestep, include/time_disc.hpp:277-289.  The caller sets the
+ * bc values for the current time first.  max_delta follows std::max's
+ * comparison, `(a < b) ? b : a` with a = |delta|. */
+ORC_API double orc_ie_timestep(orc_ie *s, double dt) {
+  orc_ie_assemble_system(s, dt);
+  double max_delta = 0.0;
+  const double *delta = orc_gmres_solve(s->solver, s->op, s->sol_vec);
+  for (int i = 0; i < s->cx; i++) {
+    for (int j = 0; j < s->cy; j++) {
+      const double d = delta[orc_cell_idx(s, i, j)];
+      AT(s, 0, i, j) += d;
+      const double a = fabs(d);
+      max_delta = (a < max_delta) ? max_delta : a;
+    }
+  }
+  s->time += dt;
+  return max_delta;
+}
+
+ORC_API double orc_ie_time(const orc_ie *s) { return s->time; }
+ORC_API long orc_ie_num_eqns(const orc_ie *s) { return s->n; }
+ORC_API int64_t orc_ie_nnz(const orc_ie *s) { return s->rowptr[s->n]; }
+ORC_API const double *orc_ie_field(const orc_ie *s, int f) { return s->fld[f]; }
+ORC_API double *orc_ie_field_mut(orc_ie *s, int f) { return s->fld[f]; }
+ORC_API const int64_t *orc_ie_rowptr(const orc_ie *s) { return s->rowptr; }
+ORC_API const int32_t *orc_ie_col(const orc_ie *s) { return s->col; }
+ORC_API const double *orc_ie_val(const orc_ie *s) { return s->val; }
+ORC_API const double *orc_ie_sol_vec(const orc_ie *s) { return s->sol_vec; }
+ORC_API orc_gmres *orc_ie_solver(orc_ie *s) { return s->solver; }
+ORC_API const orc_op *orc_ie_op(const orc_ie *s) { return s->op; }
+ORC_API double orc_ie_dx(const orc_ie *s) { return s->dx; }
+ORC_API double orc_ie_dy(const orc_ie *s) { return s->dy; }
