@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the implicit-Euler / GMRES hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one implicit-Euler time step (ghost fill, right-hand side,
+fixed-m GMRES cycle with modified Gram-Schmidt, state update) on a synthetic
+closed-form mesh that is resident in HBM before the timed region starts.  The
+headline value is Arnoldi iterations per second (m iterations per step).
+
+At N = 1 the workload is BASELINE.json's 8192 x 8192 mesh with GMRES(50).  For
+N > 1 the same mesh is split into row blocks, one rank per GPU (strong
+scaling), with halo exchange and all-reduced dot products over RCCL.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel (one Gram-Schmidt link, 32 B per unknown)
+                 timed live with HIP events on the stream it runs on;
+  cpu_baseline : the single-threaded CPU restatement (oracle/) timed on this
+                 box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mesh", type=int, default=8192, help="cells per side of the square mesh")
+    ap.add_argument("--m", type=int, default=50, help="GMRES subspace size (num_iters)")
+    ap.add_argument("--dt", type=float, default=0.25)
+    ap.add_argument("--graph", action="store_true", help="replay the step through a hipGraph")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-m", type=int, default=8, help="Arnoldi steps of the CPU sample cycle")
+    ap.add_argument("--cpu-mesh", type=int, default=0, help="mesh of the CPU sample (0: same as --mesh)")
+    return ap.parse_args()
+
+
+def cpu_baseline(mesh, m_sample, dt):
+    """Single-threaded CPU restatement on the same synthetic mesh: one
+    implicit-Euler step whose GMRES cycle is cut to m_sample Arnoldi steps."""
+    from krylov_amd import problems
+    from oracle import oracle
+    oracle.build()
+    sim = oracle.ImplicitEuler(**problems.s_iso(mesh), m=m_sample)
+    n = sim.n
+    t0 = time.perf_counter()
+    sim.timestep(dt)
+    el = time.perf_counter() - t0
+    # nominal bytes of the reference's unfused formulation for this sample
+    nominal = (104.0 * m_sample + 20.0 * m_sample * (m_sample + 1) + 8.0) * n
+    return {
+        "value": m_sample / el, "unit": "iters/s", "cores": 1, "kind": "port",
+        "sample": "same %dx%d synthetic mesh, ONE implicit step with the GMRES cycle cut to m=%d "
+                  "(Arnoldi steps j=0..%d only, which are the cheapest ones: a step j moves ~(104+40j)*N bytes), "
+                  "gcc -O2 -ffp-contract=off, 1 thread, %.1f s" % (mesh, mesh, m_sample, m_sample - 1, el),
+        "seconds": el, "nominal_gbps": nominal / el / 1e9,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from krylov_amd import dist_bench
+        return dist_bench.run(args, world, rank, local_rank)
+
+    import torch
+    from krylov_amd import capi, host, problems
+
+    ctx = host.Context(local_rank)
+    n_side, m, dt = args.mesh, args.m, args.dt
+    t_setup = time.perf_counter()
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(n_side), m=m, bc_time_dependent=False,
+                             use_graph=args.graph)
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    N = dev.n
+
+    for _ in range(args.warmup):
+        dev.timestep(dt)
+    timing = not (args.no_kernel_timing or args.graph)
+    ctx.set_kernel_timing(timing)
+    ctx.kernel_times()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = 0.0
+    for _ in range(args.steps):
+        last = dev.timestep(dt)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, cnt = ctx.kernel_times()
+    ctx.set_kernel_timing(False)
+
+    bytes_cycle, launches_cycle = dev.solver().cycle_bytes(dev.operator())
+    kernels = {}
+    for k, name in enumerate(capi.K_NAMES):
+        if cnt[k] == 0:
+            continue
+        per_launch = bytes_cycle[k] / launches_cycle[k] if launches_cycle[k] else None
+        avg_ms = ms[k] / cnt[k]
+        kernels[name] = {"launches": cnt[k], "total_ms": round(ms[k], 3), "avg_ms": round(avg_ms, 4),
+                         "alg_bytes_per_launch": per_launch,
+                         "gbps": round(per_launch / (avg_ms * 1e-3) / 1e9, 1) if per_launch else None}
+    roofline = None
+    if "mgs_link" in kernels:
+        k = kernels["mgs_link"]
+        per_launch = 32.0 * N  # read w, v_prev, v_cur; write w: 4 x 8 B per unknown
+        achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("mesh") == n_side:
+                    traffic = tj.get("mgs_link_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_mgs_step<false> (one modified-Gram-Schmidt link)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],
+                    "launches_timed": k["launches"]}
+    total_alg = sum(bytes_cycle) * args.steps
+    out = {
+        "metric": "gmres_arnoldi_iters_per_sec",
+        "value": m * args.steps / elapsed,
+        "unit": "iters/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "S-iso %dx%d mesh, implicit-Euler step with fixed-m GMRES(%d), "
+                               "modified Gram-Schmidt, 5-band stencil operator" % (n_side, n_side, m),
+                   "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
+                   "parallelism": "1 GPU", "graph": bool(args.graph)},
+        "hbm_gbps_whole_step": round(total_alg / elapsed / 1e9, 1),
+        "hbm_frac_whole_step": round(total_alg / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+        "last_max_delta": last,
+        "setup_s": round(t_setup, 2),
+        "kernels": kernels,
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n_side, args.cpu_m, dt)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,208 @@
+/*
+ * krylov_amd.h -- C ABI of the MI355X (gfx950) implementation of the
+ * implicit-Euler / GMRES path of mfdeakin/krylov.
+ *
+ * All entry points are plain C: opaque handles, plain pointers and sizes, an
+ * int status as return value (0 = KRY_OK), never an exception.  Host pointers
+ * are caller-owned; every device buffer is owned by the handle that created
+ * it.  Work is queued on the context's HIP stream; entry points that hand
+ * results back to host memory synchronise that stream before returning, the
+ * *_device entry points do not.
+ *
+ * Each declaration names the reference interface it stands in for
+ * (paths relative to the reference checkout).
+ *
+ * Vector index spaces
+ *   "cell"   : the unknown numbering of ImplicitEuler::cell_idx
+ *              (include/time_disc.hpp:341-376), N = (cx+2)(cy+2)-4 entries.
+ *   "padded" : the (cx+2) x (cy+2) row-major layout of the mesh fields
+ *              (include/mesh.hpp:77-120), j fastest, including the four unused
+ *              corner entries, which every kernel keeps at exactly 0.
+ *   The stencil operator and the solver attached to a kry_ie work in padded
+ *   space on the device; the kry_ie getters convert to cell numbering.
+ */
+#ifndef KRYLOV_AMD_H_
+#define KRYLOV_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kry_ctx kry_ctx;     /* device + stream + reduction scratch          */
+typedef struct kry_op kry_op;       /* linear operator (5-band stencil or CSR)      */
+typedef struct kry_gmres kry_gmres; /* GMRESSolver<m> / GMRESTDPSolver<m> state     */
+typedef struct kry_ie kry_ie;       /* ImplicitEuler<SecondOrderCentered, Solver>   */
+
+enum kry_status {
+  KRY_OK = 0,
+  KRY_ERR_INVALID = 1, /* bad argument / shape mismatch                  */
+  KRY_ERR_HIP = 2,     /* a HIP runtime call failed                      */
+  KRY_ERR_STATE = 3,   /* call order violated (e.g. arnoldi before init) */
+  KRY_ERR_NO_DEVICE = 4
+};
+
+/* Field / side selectors: the order of the BC arguments of the TimeDisc
+ * constructor, include/time_disc.hpp:23-50. */
+enum kry_field { KRY_FIELD_T = 0, KRY_FIELD_U = 1, KRY_FIELD_V = 2 };
+enum kry_side { KRY_SIDE_BOTTOM = 0, KRY_SIDE_TOP = 1, KRY_SIDE_LEFT = 2, KRY_SIDE_RIGHT = 3 };
+
+/* Solver flags (kry_gmres_create, kry_ie_create). */
+enum kry_gmres_flags {
+  KRY_GMRES_PLAIN = 0,
+  KRY_GMRES_TDP = 1,           /* GMRESTDPSolver: tridiagonal right preconditioner   */
+  KRY_GMRES_FIXED_PRECOND = 2, /* opt-in, not in the reference: return M^-1 u        */
+  KRY_GMRES_ORTH_CGS2 = 4      /* opt-in: classical Gram-Schmidt applied twice with
+                                  batched dot products instead of the reference's
+                                  modified Gram-Schmidt                             */
+};
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char *kry_last_error(void);
+/* Library version string. */
+const char *kry_version(void);
+int kry_device_count(int *count);
+
+/* ---- context -------------------------------------------------------------- */
+/* stream == NULL: the context creates (and owns) a stream on `device`.
+ * Otherwise `stream` is a hipStream_t the caller keeps alive. */
+int kry_ctx_create(int device, void *stream, kry_ctx **out);
+void kry_ctx_destroy(kry_ctx *ctx);
+int kry_ctx_synchronize(kry_ctx *ctx);
+/* hipStream_t of the context (for event timing by the caller). */
+void *kry_ctx_stream(kry_ctx *ctx);
+/* Optional instrumentation (off by default): bracket every kernel launch with
+ * HIP events on the context's stream and accumulate the elapsed time per
+ * kernel class (enum kry_kernel_class below).  get_kernel_times synchronises
+ * the stream, returns the totals since the previous call and resets them. */
+int kry_ctx_set_kernel_timing(kry_ctx *ctx, int on);
+int kry_ctx_get_kernel_times(kry_ctx *ctx, double ms[], int launches[]);
+
+/* ---- operators: stand-ins for the dense `matrix` handed to Solver::solve ----
+ * reference: dot(vector&, const matrix&, const vector&), include/matrix.hpp:23-33 */
+
+/* Five coefficient bands on a rows x cols padded grid (host arrays of
+ * rows*cols doubles each): y[k] = w[k] x[k-cols] + s[k] x[k-1] + c[k] x[k]
+ * + n[k] x[k+1] + e[k] x[k+cols], summed in that (ascending column) order. */
+int kry_op_create_stencil(kry_ctx *ctx, int rows, int cols, const double *w,
+                          const double *s, const double *c, const double *n,
+                          const double *e, kry_op **out);
+/* CSR with ascending column indices per row. */
+int kry_op_create_csr(kry_ctx *ctx, int64_t n, const int64_t *rowptr,
+                      const int32_t *col, const double *val, kry_op **out);
+/* Row-major dense n x n matrix (the reference's `matrix`); stored entries that
+ * are exactly 0.0 are dropped, the rest becomes CSR.
+ * reference: Matrix.from_array, src/bindpy.cpp:618-629 */
+int kry_op_create_dense(kry_ctx *ctx, int64_t n, const double *a, kry_op **out);
+void kry_op_destroy(kry_op *op);
+int64_t kry_op_size(const kry_op *op);
+/* y = A x for host vectors of kry_op_size entries.
+ * reference: include/matrix.hpp:23-33 */
+int kry_op_apply(kry_op *op, const double *x_host, double *y_host);
+/* Same on device pointers, asynchronous on the context's stream. */
+int kry_op_apply_device(kry_op *op, const double *x_dev, double *y_dev);
+
+/* ---- GMRES: include/solver.hpp:115-239 (GMRESSolver<m>), :279-333 (TDP) ----- */
+int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out);
+void kry_gmres_destroy(kry_gmres *g);
+/* GMRESSolver::initial_subspace, include/solver.hpp:168-174; *beta = ||b||. */
+int kry_gmres_initial_subspace(kry_gmres *g, const double *b_host, double *beta);
+/* GMRESTDPSolver::assemble_preconditioner, include/solver.hpp:295-314.
+ * tdiags_host (may be NULL) receives the n x 3 band copy (entries (0,0) and
+ * (n-1,2) are NaN as in the reference). */
+int kry_gmres_assemble_preconditioner(kry_gmres *g, kry_op *op, double *tdiags_host);
+/* GMRESSolver::add_arnoldi (include/solver.hpp:185-194) or the TDP override
+ * (:316-328), incl. gram_schmidt (:196-211); *h_next = H(j+1, j). */
+int kry_gmres_add_arnoldi(kry_gmres *g, kry_op *op, double *h_next);
+/* GMRESSolver::solve / GMRESTDPSolver::solve, include/solver.hpp:124-161,
+ * :290-293; x_host may be NULL (fetch later with kry_gmres_prev_result). */
+int kry_gmres_solve(kry_gmres *g, kry_op *op, const double *b_host, double *x_host);
+/* Same with device pointers (n entries each), asynchronous, no host sync:
+ * one whole fixed-m cycle queued on the stream. x_dev may be NULL. */
+int kry_gmres_solve_device(kry_gmres *g, kry_op *op, const double *b_dev, double *x_dev);
+/* GMRESSolver::subspace_vector, include/solver.hpp:163-166 */
+int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host);
+/* GMRESSolver::hessenberg, include/solver.hpp:176-181 */
+int kry_gmres_hessenberg(kry_gmres *g, int i, int j, double *out);
+/* Whole (m+1) x m row-major Hessenberg array. */
+int kry_gmres_hessenberg_matrix(kry_gmres *g, double *out_host);
+/* Solver::prev_result, include/solver.hpp:21 (signalling NaN before a solve). */
+int kry_gmres_prev_result(kry_gmres *g, double *out_host);
+/* Device pointer to the n-entry result vector. */
+const double *kry_gmres_result_device(kry_gmres *g);
+int64_t kry_gmres_size(const kry_gmres *g);
+int kry_gmres_iterations(const kry_gmres *g);
+/* Kernel-level timing hooks for the benchmark: algorithmic bytes moved by the
+ * kernels of one full cycle, per class (see kry_kernel_class). */
+enum kry_kernel_class {
+  KRY_K_SPMV = 0,      /* operator apply fused with <w, v_0>                    */
+  KRY_K_MGS = 1,       /* Gram-Schmidt link: w -= h v_prev, <w, v_cur>          */
+  KRY_K_MGS_LAST = 2,  /* last link of a step: w -= h v_j, <w, w>               */
+  KRY_K_NORMALIZE = 3, /* v = w / ||w|| (and v_0 = b / ||b||)                   */
+  KRY_K_COMBINE = 4,   /* x = sum y_i v_i                                       */
+  KRY_K_PRECOND = 5,   /* tridiagonal line solves                               */
+  KRY_K_ASSEMBLY = 6,  /* ghost fill, right-hand side, state update             */
+  KRY_K_OTHER = 7,     /* reduced m x m solve                                   */
+  KRY_K_COUNT = 8
+};
+int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY_K_COUNT],
+                          int launches[KRY_K_COUNT]);
+
+/* ---- the implicit-Euler step: include/time_disc.hpp ------------------------- */
+/* Mesh + TimeDisc + ImplicitEuler constructor, first half
+ * (src/mesh.cpp:8-68, include/time_disc.hpp:17-134, :196-245).
+ * T0/u0/v0: interior values sampled at the cell medians, cx*cy row-major
+ * (i slow, j fast).  bc_is_dirichlet[field*4+side].  m, flags: the solver. */
+int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y,
+                  int cx, int cy, const double *T0, const double *u0,
+                  const double *v0, double diffusion, double reynolds,
+                  double prandtl, double eckert, const int *bc_is_dirichlet,
+                  int m, int flags, kry_ie **out);
+void kry_ie_destroy(kry_ie *ie);
+/* bc(x, y, t) sampled by the host at the boundary-cell coordinates of
+ * include/time_disc.hpp:55-76 for one field and side (cx values for
+ * bottom/top, cy for left/right); consumed by the next ghost fill. */
+int kry_ie_set_bc_values(kry_ie *ie, int field, int side, const double *vals, int len);
+/* TimeDisc::apply_bcs, include/time_disc.hpp:146-163 (+ the constructor's
+ * view wiring, :51-134) */
+int kry_ie_apply_bcs(kry_ie *ie);
+/* ImplicitEuler constructor, second half (include/time_disc.hpp:246-274):
+ * ghost fill at t = 0 and the four off-diagonal bands (never refreshed). */
+int kry_ie_init_offdiag(kry_ie *ie);
+/* ImplicitEuler::assemble_system, include/time_disc.hpp:291-339 */
+int kry_ie_assemble_system(kry_ie *ie, double dt);
+/* ImplicitEuler::timestep, include/time_disc.hpp:277-289.  *max_delta is the
+ * largest |delta| over interior cells (NaN if any of them is NaN). */
+int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta);
+/* The same step queued without reading max|delta| back (for back-to-back
+ * steps with time-independent boundary values); fetch with kry_ie_last_max_delta. */
+int kry_ie_timestep_async(kry_ie *ie, double dt);
+int kry_ie_last_max_delta(kry_ie *ie, double *max_delta);
+/* Replay the step through a captured hipGraph (1) or launch kernels eagerly (0). */
+int kry_ie_use_graph(kry_ie *ie, int on);
+/* TimeDisc::cur_time, include/time_disc.hpp:138 */
+double kry_ie_time(const kry_ie *ie);
+int64_t kry_ie_num_eqns(const kry_ie *ie);
+/* Mesh::array_Temp / array_vel_u / array_vel_v (include/mesh.hpp:251-257):
+ * (cx+2)*(cy+2) doubles, corners are NaN. */
+int kry_ie_get_field(kry_ie *ie, int field, double *out_padded);
+/* ImplicitEuler::sys (include/time_disc.hpp:378) as a dense N x N row-major
+ * matrix in cell numbering (small meshes only: N*N doubles). */
+int kry_ie_get_dense_system(kry_ie *ie, double *out);
+/* The five bands (w, s, c, n, e), each (cx+2)*(cy+2) doubles, padded layout. */
+int kry_ie_get_bands(kry_ie *ie, double *out5);
+/* ImplicitEuler::sol (include/time_disc.hpp:379), N entries, cell numbering. */
+int kry_ie_get_rhs(kry_ie *ie, double *out);
+/* ImplicitEuler::delta (include/time_disc.hpp:380), N entries, cell numbering. */
+int kry_ie_get_delta(kry_ie *ie, double *out);
+/* The solver / operator owned by the step object (borrowed handles). */
+kry_gmres *kry_ie_solver(kry_ie *ie);
+kry_op *kry_ie_operator(kry_ie *ie);
+/* Device pointer of the padded right-hand side (for benchmarks). */
+const double *kry_ie_rhs_device(kry_ie *ie);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRYLOV_AMD_H_ */

@@ -1,0 +1,1100 @@
+// C ABI of libkrylov_amd: handle management and the host-side orchestration of
+// the device kernels.  No host synchronisation happens inside a GMRES cycle or
+// inside an implicit-Euler step; results are read back only where the ABI
+// hands host memory to the caller.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "kry_internal.h"
+
+using namespace kry;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(KRY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+#define KCHK(expr)            \
+  do {                        \
+    int s_ = (expr);          \
+    if (s_ != KRY_OK) return s_; \
+  } while (0)
+
+static const double kSNaN = std::numeric_limits<double>::signaling_NaN();
+
+// ---------------------------------------------------------------------------
+// Handles
+// ---------------------------------------------------------------------------
+struct KernelRec {
+  int cls;
+  hipEvent_t a, b;
+};
+
+struct kry_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // optional per-kernel-class timing with HIP events on `stream`
+  // handles created on this context keep it alive: destroy order is free
+  int refs = 0;
+  bool released = false;
+  bool timing = false;
+  std::vector<hipEvent_t> free_events;
+  std::vector<KernelRec> recs;
+};
+
+// Brackets the launches issued in its scope with two events on the context's
+// stream when timing is enabled; a no-op otherwise.
+struct ScopedKernelTimer {
+  kry_ctx *c;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  static hipEvent_t get(kry_ctx *c) {
+    hipEvent_t e = nullptr;
+    if (!c->free_events.empty()) {
+      e = c->free_events.back();
+      c->free_events.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+    }
+    return e;
+  }
+  ScopedKernelTimer(kry_ctx *ctx, int k) : c(ctx), cls(k) {
+    if (!c->timing) return;
+    a = get(c);
+    b = get(c);
+    if (a) (void)hipEventRecord(a, c->stream);
+  }
+  ~ScopedKernelTimer() {
+    if (!c->timing || !a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->recs.push_back({cls, a, b});
+  }
+};
+
+struct kry_op {
+  kry_ctx *ctx = nullptr;
+  int kind = 0;  // 0 stencil, 1 csr
+  int64_t n = 0;
+  int rows = 0, cols = 0;
+  double *band[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool own_bands = false;
+  int64_t *rowptr = nullptr;
+  int32_t *col = nullptr;
+  double *val = nullptr;
+  int64_t nnz = 0;
+  double *tx = nullptr, *ty = nullptr;  // staging for the host apply
+};
+
+struct kry_gmres {
+  kry_ctx *ctx = nullptr;
+  int64_t n = 0, ld = 0;
+  int m = 0, flags = 0;
+  int nvec = 0;  // subspace.size()
+  double *V = nullptr;      // (m+1) x ld
+  double *H = nullptr;      // (m+1) x m
+  double *w = nullptr;      // Arnoldi work vector
+  double *z = nullptr;      // preconditioned vector
+  double *vars = nullptr;   // Solver::vars
+  double *parts = nullptr;  // 2 x kMaxParts
+  double *beta = nullptr;   // 1
+  double *y = nullptr;      // m
+  double *work = nullptr;   // 3 m^2 + 2 m
+  double *bbuf = nullptr;   // staging of a host right-hand side
+  // tridiagonal preconditioner
+  double *lo = nullptr, *di = nullptr, *up = nullptr;  // owned only for CSR operators
+  bool own_tri = false;
+  double *dd = nullptr, *ud = nullptr;
+  int64_t nlines = 0, L = 0;
+  bool tdp_ready = false;
+};
+
+struct kry_ie {
+  kry_ctx *ctx = nullptr;
+  IeGeom g;
+  IeBc bc;
+  double min_x, min_y;
+  int64_t npad = 0, neq = 0;
+  double *fld[3] = {nullptr, nullptr, nullptr};
+  double *band[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *rhs = nullptr;
+  double *bcvals = nullptr;    // device, 3 * 2 (cx+cy)
+  double *bcvals_h = nullptr;  // pinned staging
+  bool bc_dirty = true;
+  double *parts = nullptr;
+  double *maxd = nullptr;    // device scalar
+  double *maxd_h = nullptr;  // pinned
+  double time = 0.0;
+  kry_op *op = nullptr;
+  kry_gmres *solver = nullptr;
+  bool pending = false;  // work queued whose result has not been waited for
+  // hipGraph replay of the step
+  bool use_graph = false;
+  hipGraphExec_t graph_exec = nullptr;
+  double graph_dt = 0.0;
+};
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char *kry_last_error(void) { return g_err.c_str(); }
+const char *kry_version(void) { return "krylov_amd 0.1 (gfx950)"; }
+
+int kry_device_count(int *count) {
+  if (!count) return fail(KRY_ERR_INVALID, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(KRY_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = c;
+  return KRY_OK;
+}
+
+int kry_ctx_create(int device, void *stream, kry_ctx **out) {
+  if (!out) return fail(KRY_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+    return fail(KRY_ERR_NO_DEVICE, "no HIP device is visible; the HIP path cannot run");
+  if (device < 0 || device >= c) return fail(KRY_ERR_INVALID, "device %d out of range (%d devices)", device, c);
+  HIPCHK(hipSetDevice(device));
+  kry_ctx *ctx = new kry_ctx;
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(KRY_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return KRY_OK;
+}
+
+static void ctx_free(kry_ctx *ctx);
+
+static void ctx_ref(kry_ctx *ctx) { ctx->refs++; }
+static void ctx_unref(kry_ctx *ctx) {
+  if (--ctx->refs == 0 && ctx->released) ctx_free(ctx);
+}
+
+void kry_ctx_destroy(kry_ctx *ctx) {
+  if (!ctx || ctx->released) return;
+  ctx->released = true;
+  if (ctx->refs == 0) ctx_free(ctx);
+}
+
+static void ctx_free(kry_ctx *ctx) {
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &r : ctx->recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int kry_ctx_synchronize(kry_ctx *ctx) {
+  if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return KRY_OK;
+}
+
+void *kry_ctx_stream(kry_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int kry_ctx_set_kernel_timing(kry_ctx *ctx, int on) {
+  if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
+  ctx->timing = on != 0;
+  return KRY_OK;
+}
+
+int kry_ctx_get_kernel_times(kry_ctx *ctx, double ms[], int launches[]) {
+  if (!ctx || !ms || !launches) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < KRY_K_COUNT; k++) {
+    ms[k] = 0.0;
+    launches[k] = 0;
+  }
+  for (auto &r : ctx->recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      ms[r.cls] += (double)t;
+      launches[r.cls] += 1;
+    }
+    ctx->free_events.push_back(r.a);
+    ctx->free_events.push_back(r.b);
+  }
+  ctx->recs.clear();
+  return KRY_OK;
+}
+
+}  // extern "C"
+
+static int dev_alloc(double **p, int64_t count) {
+  *p = nullptr;
+  HIPCHK(hipMalloc((void **)p, sizeof(double) * (size_t)(count > 0 ? count : 1)));
+  return KRY_OK;
+}
+
+static int launch_ok(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(KRY_ERR_HIP, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
+  return KRY_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Operators
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int kry_op_create_stencil(kry_ctx *ctx, int rows, int cols, const double *w, const double *s,
+                          const double *c, const double *n, const double *e, kry_op **out) {
+  if (!ctx || !out || !w || !s || !c || !n || !e) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (rows < 1 || cols < 1) return fail(KRY_ERR_INVALID, "rows/cols must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  kry_op *op = new kry_op;
+  op->ctx = ctx;
+  ctx_ref(ctx);
+  op->kind = 0;
+  op->rows = rows;
+  op->cols = cols;
+  op->n = (int64_t)rows * cols;
+  op->own_bands = true;
+  const double *src[5] = {w, s, c, n, e};
+  for (int b = 0; b < 5; b++) {
+    int st = dev_alloc(&op->band[b], op->n);
+    if (st == KRY_OK && hipMemcpy(op->band[b], src[b], sizeof(double) * op->n, hipMemcpyHostToDevice) != hipSuccess)
+      st = fail(KRY_ERR_HIP, "band upload failed");
+    if (st != KRY_OK) {
+      kry_op_destroy(op);
+      return st;
+    }
+  }
+  *out = op;
+  return KRY_OK;
+}
+
+int kry_op_create_csr(kry_ctx *ctx, int64_t n, const int64_t *rowptr, const int32_t *col,
+                      const double *val, kry_op **out) {
+  if (!ctx || !out || !rowptr || (!col && rowptr[n] > 0) || (!val && rowptr[n] > 0))
+    return fail(KRY_ERR_INVALID, "NULL argument");
+  if (n < 1) return fail(KRY_ERR_INVALID, "n must be positive");
+  if (rowptr[0] != 0) return fail(KRY_ERR_INVALID, "rowptr[0] must be 0");
+  for (int64_t r = 0; r < n; r++) {
+    if (rowptr[r + 1] < rowptr[r]) return fail(KRY_ERR_INVALID, "rowptr not monotone at row %lld", (long long)r);
+    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+      if (col[p] < 0 || col[p] >= n) return fail(KRY_ERR_INVALID, "column index out of range in row %lld", (long long)r);
+      if (p > rowptr[r] && col[p] <= col[p - 1])
+        return fail(KRY_ERR_INVALID, "columns of row %lld are not strictly ascending", (long long)r);
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  kry_op *op = new kry_op;
+  op->ctx = ctx;
+  ctx_ref(ctx);
+  op->kind = 1;
+  op->n = n;
+  op->nnz = rowptr[n];
+  const size_t nz = (size_t)(op->nnz > 0 ? op->nnz : 1);
+  if (hipMalloc((void **)&op->rowptr, sizeof(int64_t) * (size_t)(n + 1)) != hipSuccess ||
+      hipMalloc((void **)&op->col, sizeof(int32_t) * nz) != hipSuccess ||
+      hipMalloc((void **)&op->val, sizeof(double) * nz) != hipSuccess ||
+      hipMemcpy(op->rowptr, rowptr, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice) != hipSuccess ||
+      (op->nnz > 0 && hipMemcpy(op->col, col, sizeof(int32_t) * nz, hipMemcpyHostToDevice) != hipSuccess) ||
+      (op->nnz > 0 && hipMemcpy(op->val, val, sizeof(double) * nz, hipMemcpyHostToDevice) != hipSuccess)) {
+    kry_op_destroy(op);
+    return fail(KRY_ERR_HIP, "CSR upload failed");
+  }
+  *out = op;
+  return KRY_OK;
+}
+
+int kry_op_create_dense(kry_ctx *ctx, int64_t n, const double *a, kry_op **out) {
+  if (!ctx || !out || !a) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (n < 1) return fail(KRY_ERR_INVALID, "n must be positive");
+  std::vector<int64_t> rowptr((size_t)n + 1, 0);
+  std::vector<int32_t> col;
+  std::vector<double> val;
+  for (int64_t r = 0; r < n; r++) {
+    for (int64_t c = 0; c < n; c++) {
+      const double v = a[r * n + c];
+      if (v != 0.0) {  // NaN != 0 is true: non-finite entries are kept
+        col.push_back((int32_t)c);
+        val.push_back(v);
+      }
+    }
+    rowptr[(size_t)r + 1] = (int64_t)col.size();
+  }
+  return kry_op_create_csr(ctx, n, rowptr.data(), col.data(), val.data(), out);
+}
+
+void kry_op_destroy(kry_op *op) {
+  if (!op) return;
+  (void)hipSetDevice(op->ctx->device);
+  if (op->own_bands)
+    for (int b = 0; b < 5; b++) (void)hipFree(op->band[b]);
+  (void)hipFree(op->rowptr);
+  (void)hipFree(op->col);
+  (void)hipFree(op->val);
+  (void)hipFree(op->tx);
+  (void)hipFree(op->ty);
+  kry_ctx *ctx = op->ctx;
+  delete op;
+  ctx_unref(ctx);
+}
+
+int64_t kry_op_size(const kry_op *op) { return op ? op->n : 0; }
+
+}  // extern "C"
+
+// y = A x; optionally the partial sums of <y, vdot>
+static void op_apply_async(kry_op *op, const double *x, double *y, const double *vdot, double *part,
+                           int *nparts) {
+  hipStream_t st = op->ctx->stream;
+  if (op->kind == 0) {
+    Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
+    launch_spmv_stencil(st, b, op->n, op->cols, x, y, vdot, part, nparts);
+  } else {
+    launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, vdot, part, nparts);
+  }
+}
+
+extern "C" {
+
+int kry_op_apply_device(kry_op *op, const double *x_dev, double *y_dev) {
+  if (!op || !x_dev || !y_dev) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (x_dev == y_dev) return fail(KRY_ERR_INVALID, "x and y must not alias");
+  HIPCHK(hipSetDevice(op->ctx->device));
+  op_apply_async(op, x_dev, y_dev, nullptr, nullptr, nullptr);
+  return launch_ok("kry_op_apply_device");
+}
+
+int kry_op_apply(kry_op *op, const double *x_host, double *y_host) {
+  if (!op || !x_host || !y_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(op->ctx->device));
+  if (!op->tx) KCHK(dev_alloc(&op->tx, op->n));
+  if (!op->ty) KCHK(dev_alloc(&op->ty, op->n));
+  hipStream_t st = op->ctx->stream;
+  HIPCHK(hipMemcpyAsync(op->tx, x_host, sizeof(double) * op->n, hipMemcpyHostToDevice, st));
+  op_apply_async(op, op->tx, op->ty, nullptr, nullptr, nullptr);
+  KCHK(launch_ok("kry_op_apply"));
+  HIPCHK(hipMemcpyAsync(y_host, op->ty, sizeof(double) * op->n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return KRY_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// GMRES
+// ---------------------------------------------------------------------------
+static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld; }
+
+extern "C" {
+
+int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out) {
+  if (!ctx || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (n < 1) return fail(KRY_ERR_INVALID, "system size must be positive");
+  if (m < 1 || m > kMaxM) return fail(KRY_ERR_INVALID, "num_iters must be in [1, %d]", kMaxM);
+  HIPCHK(hipSetDevice(ctx->device));
+  kry_gmres *g = new kry_gmres;
+  g->ctx = ctx;
+  ctx_ref(ctx);
+  g->n = n;
+  g->ld = (n + 31) / 32 * 32;  // 256-byte multiple: every basis vector is 16-byte aligned
+  g->m = m;
+  g->flags = flags;
+  int st = KRY_OK;
+  if (st == KRY_OK) st = dev_alloc(&g->V, (int64_t)(m + 1) * g->ld);
+  if (st == KRY_OK) st = dev_alloc(&g->H, (int64_t)(m + 1) * m);
+  if (st == KRY_OK) st = dev_alloc(&g->w, g->ld);
+  if (st == KRY_OK) st = dev_alloc(&g->vars, g->ld);
+  if (st == KRY_OK) st = dev_alloc(&g->parts, 2 * kMaxParts);
+  if (st == KRY_OK) st = dev_alloc(&g->beta, 1);
+  if (st == KRY_OK) st = dev_alloc(&g->y, m);
+  if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 2 * m);
+  if (st == KRY_OK && (flags & KRY_GMRES_TDP)) {
+    st = dev_alloc(&g->z, g->ld);
+    if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
+    if (st == KRY_OK) st = dev_alloc(&g->ud, g->ld);
+  }
+  if (st != KRY_OK) {
+    kry_gmres_destroy(g);
+    return st;
+  }
+  hipStream_t s = ctx->stream;
+  launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
+  (void)hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(m + 1) * m, s);
+  (void)hipMemsetAsync(g->V, 0, sizeof(double) * (size_t)(m + 1) * g->ld, s);
+  (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
+  st = launch_ok("kry_gmres_create");
+  if (st == KRY_OK && hipStreamSynchronize(s) != hipSuccess) st = fail(KRY_ERR_HIP, "sync failed");
+  if (st != KRY_OK) {
+    kry_gmres_destroy(g);
+    return st;
+  }
+  *out = g;
+  return KRY_OK;
+}
+
+void kry_gmres_destroy(kry_gmres *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  double *bufs[] = {g->V, g->H, g->w, g->z, g->vars, g->parts, g->beta, g->y, g->work, g->bbuf, g->dd, g->ud};
+  for (double *p : bufs) (void)hipFree(p);
+  if (g->own_tri) {
+    (void)hipFree(g->lo);
+    (void)hipFree(g->di);
+    (void)hipFree(g->up);
+  }
+  kry_ctx *ctx = g->ctx;
+  delete g;
+  ctx_unref(ctx);
+}
+
+int64_t kry_gmres_size(const kry_gmres *g) { return g ? g->n : 0; }
+int kry_gmres_iterations(const kry_gmres *g) { return g ? g->m : 0; }
+const double *kry_gmres_result_device(kry_gmres *g) { return g ? g->vars : nullptr; }
+
+}  // extern "C"
+
+static int check_op(kry_gmres *g, kry_op *op) {
+  if (!g || !op) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (op->n != g->n) return fail(KRY_ERR_INVALID, "operator size %lld != solver size %lld", (long long)op->n, (long long)g->n);
+  if (op->ctx != g->ctx) return fail(KRY_ERR_INVALID, "operator and solver belong to different contexts");
+  return KRY_OK;
+}
+
+// GMRESTDPSolver::assemble_preconditioner + the rhs-independent half of
+// SparseTriDiagSolver::solve.
+static int tdp_setup_async(kry_gmres *g, kry_op *op) {
+  hipStream_t st = g->ctx->stream;
+  if (op->kind == 0) {
+    if (g->own_tri) return fail(KRY_ERR_STATE, "solver was set up for a CSR operator");
+    g->lo = op->band[1];
+    g->di = op->band[2];
+    g->up = op->band[3];
+    g->nlines = op->rows;
+    g->L = op->cols;
+  } else {
+    if (!g->own_tri) {
+      KCHK(dev_alloc(&g->lo, g->ld));
+      KCHK(dev_alloc(&g->di, g->ld));
+      KCHK(dev_alloc(&g->up, g->ld));
+      g->own_tri = true;
+    }
+    launch_tdp_extract_csr(st, op->rowptr, op->col, op->val, op->n, g->lo, g->di, g->up);
+    g->nlines = 1;
+    g->L = g->n;
+  }
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
+    launch_tdp_factor(st, g->lo, g->di, g->up, g->dd, g->ud, g->nlines, g->L);
+  }
+  g->tdp_ready = true;
+  return launch_ok("tdp_setup");
+}
+
+static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
+  hipStream_t st = g->ctx->stream;
+  int np = 0;
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
+    launch_nrm2_part(st, b_dev, g->n, g->parts, &np);
+    launch_scale_from(st, b_dev, basis(g, 0), g->parts, np, g->n, g->beta);
+  }
+  g->nvec = 1;
+  return launch_ok("initial_subspace");
+}
+
+// One Arnoldi step with the fused modified Gram-Schmidt chain.
+static int arnoldi_async(kry_gmres *g, kry_op *op) {
+  if (g->nvec < 1) return fail(KRY_ERR_STATE, "add_arnoldi before initial_subspace");
+  const int j = g->nvec - 1;
+  if (j >= g->m) return fail(KRY_ERR_STATE, "subspace is full (%d vectors for num_iters = %d)", g->nvec, g->m);
+  hipStream_t st = g->ctx->stream;
+  const int64_t n = g->n;
+  double *part[2] = {g->parts, g->parts + kMaxParts};
+  int np[2] = {0, 0};
+  const double *src = basis(g, j);
+  if (g->flags & KRY_GMRES_TDP) {
+    if (!g->tdp_ready) return fail(KRY_ERR_STATE, "preconditioner has not been assembled");
+    ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
+    launch_tdp_apply(st, g->lo, g->dd, g->ud, src, g->z, g->nlines, g->L);
+    src = g->z;
+  }
+  {
+    // w = A v_j and the partial sums of <w, v_0>
+    ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
+    op_apply_async(op, src, g->w, basis(g, 0), part[0], &np[0]);
+  }
+  for (int i = 1; i <= j; i++) {
+    ScopedKernelTimer t(g->ctx, KRY_K_MGS);
+    launch_mgs_step(st, g->w, basis(g, i - 1), basis(g, i), part[(i - 1) & 1], np[(i - 1) & 1],
+                    part[i & 1], &np[i & 1], g->H + (int64_t)(i - 1) * g->m + j, n);
+  }
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
+    launch_mgs_step(st, g->w, basis(g, j), nullptr, part[j & 1], np[j & 1], part[(j + 1) & 1],
+                    &np[(j + 1) & 1], g->H + (int64_t)j * g->m + j, n);
+  }
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
+    launch_scale_from(st, g->w, basis(g, j + 1), part[(j + 1) & 1], np[(j + 1) & 1], n,
+                      g->H + (int64_t)(j + 1) * g->m + j);
+  }
+  g->nvec++;
+  return launch_ok("add_arnoldi");
+}
+
+static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_dev) {
+  hipStream_t st = g->ctx->stream;
+  if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
+  KCHK(initial_subspace_async(g, b_dev));
+  HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
+  for (int i = 0; i < g->m; i++) KCHK(arnoldi_async(g, op));
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+    launch_small_solve(st, g->H, g->beta, g->m, g->y, g->work);
+  }
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
+    launch_combine(st, g->V, g->ld, g->y, g->m, g->vars, g->n);
+  }
+  if ((g->flags & KRY_GMRES_TDP) && (g->flags & KRY_GMRES_FIXED_PRECOND)) {
+    launch_tdp_apply(st, g->lo, g->dd, g->ud, g->vars, g->z, g->nlines, g->L);
+    HIPCHK(hipMemcpyAsync(g->vars, g->z, sizeof(double) * g->n, hipMemcpyDeviceToDevice, st));
+  }
+  KCHK(launch_ok("solve"));
+  if (x_dev) HIPCHK(hipMemcpyAsync(x_dev, g->vars, sizeof(double) * g->n, hipMemcpyDeviceToDevice, st));
+  return KRY_OK;
+}
+
+static int stage_rhs(kry_gmres *g, const double *b_host) {
+  if (!g->bbuf) KCHK(dev_alloc(&g->bbuf, g->ld));
+  HIPCHK(hipMemcpyAsync(g->bbuf, b_host, sizeof(double) * g->n, hipMemcpyHostToDevice, g->ctx->stream));
+  return KRY_OK;
+}
+
+extern "C" {
+
+int kry_gmres_initial_subspace(kry_gmres *g, const double *b_host, double *beta) {
+  if (!g || !b_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  KCHK(stage_rhs(g, b_host));
+  KCHK(initial_subspace_async(g, g->bbuf));
+  double b = 0.0;
+  HIPCHK(hipMemcpyAsync(&b, g->beta, sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  if (beta) *beta = b;
+  return KRY_OK;
+}
+
+int kry_gmres_assemble_preconditioner(kry_gmres *g, kry_op *op, double *tdiags_host) {
+  KCHK(check_op(g, op));
+  if (!(g->flags & KRY_GMRES_TDP)) return fail(KRY_ERR_STATE, "solver was created without KRY_GMRES_TDP");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  KCHK(tdp_setup_async(g, op));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  if (tdiags_host) {
+    const int64_t n = g->n;
+    std::vector<double> lo((size_t)n), di((size_t)n), up((size_t)n);
+    HIPCHK(hipMemcpy(lo.data(), g->lo, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(di.data(), g->di, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(up.data(), g->up, sizeof(double) * n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) {
+      tdiags_host[i * 3 + 0] = lo[(size_t)i];
+      tdiags_host[i * 3 + 1] = di[(size_t)i];
+      tdiags_host[i * 3 + 2] = up[(size_t)i];
+    }
+    tdiags_host[0] = kSNaN;               // include/solver.hpp:297
+    tdiags_host[(n - 1) * 3 + 2] = kSNaN; // include/solver.hpp:312
+  }
+  return KRY_OK;
+}
+
+int kry_gmres_add_arnoldi(kry_gmres *g, kry_op *op, double *h_next) {
+  KCHK(check_op(g, op));
+  HIPCHK(hipSetDevice(g->ctx->device));
+  KCHK(arnoldi_async(g, op));
+  const int j = g->nvec - 2;
+  double h = 0.0;
+  HIPCHK(hipMemcpyAsync(&h, g->H + (int64_t)(j + 1) * g->m + j, sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  if (h_next) *h_next = h;
+  return KRY_OK;
+}
+
+int kry_gmres_solve_device(kry_gmres *g, kry_op *op, const double *b_dev, double *x_dev) {
+  KCHK(check_op(g, op));
+  if (!b_dev) return fail(KRY_ERR_INVALID, "b is NULL");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  return solve_async(g, op, b_dev, x_dev);
+}
+
+int kry_gmres_solve(kry_gmres *g, kry_op *op, const double *b_host, double *x_host) {
+  KCHK(check_op(g, op));
+  if (!b_host) return fail(KRY_ERR_INVALID, "b is NULL");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  KCHK(stage_rhs(g, b_host));
+  KCHK(solve_async(g, op, g->bbuf, nullptr));
+  if (x_host) HIPCHK(hipMemcpyAsync(x_host, g->vars, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return KRY_OK;
+}
+
+int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
+  if (!g || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (i < 0 || i >= g->nvec) return fail(KRY_ERR_INVALID, "subspace vector %d does not exist (%d vectors)", i, g->nvec);
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpyAsync(out_host, basis(g, i), sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return KRY_OK;
+}
+
+int kry_gmres_hessenberg(kry_gmres *g, int i, int j, double *out) {
+  if (!g || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (i < 0 || i > g->m || j < 0 || j >= g->m) return fail(KRY_ERR_INVALID, "H(%d,%d) out of range", i, j);
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpyAsync(out, g->H + (int64_t)i * g->m + j, sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return KRY_OK;
+}
+
+int kry_gmres_hessenberg_matrix(kry_gmres *g, double *out_host) {
+  if (!g || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpyAsync(out_host, g->H, sizeof(double) * (size_t)(g->m + 1) * g->m, hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return KRY_OK;
+}
+
+int kry_gmres_prev_result(kry_gmres *g, double *out_host) {
+  if (!g || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpyAsync(out_host, g->vars, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return KRY_OK;
+}
+
+// Algorithmic bytes (each operand read once, each result written once per
+// kernel) of one fixed-m cycle, per kernel class.
+int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY_K_COUNT],
+                          int launches[KRY_K_COUNT]) {
+  if (!g || !op || !bytes || !launches) return fail(KRY_ERR_INVALID, "NULL argument");
+  for (int k = 0; k < KRY_K_COUNT; k++) {
+    bytes[k] = 0.0;
+    launches[k] = 0;
+  }
+  const double N = 8.0 * (double)g->n;  // bytes of one vector
+  const int m = g->m;
+  // operator apply fused with the first dot: bands/CSR + x + v_0 read, y written
+  double spmv = op->kind == 0 ? 5.0 * N + 3.0 * N
+                              : 12.0 * (double)op->nnz + 8.0 * (double)(op->n + 1) + 3.0 * N;
+  bytes[KRY_K_SPMV] = spmv * m;
+  launches[KRY_K_SPMV] = m;
+  // chain links: read w, v_prev, v_cur, write w (4N); last link of a step: 3N
+  for (int j = 0; j < m; j++) {
+    bytes[KRY_K_MGS] += 4.0 * N * j;
+    launches[KRY_K_MGS] += j;
+    bytes[KRY_K_MGS_LAST] += 3.0 * N;
+    launches[KRY_K_MGS_LAST] += 1;
+  }
+  bytes[KRY_K_NORMALIZE] = 2.0 * N * m + 3.0 * N;  // m normalisations + ||b|| and v_0 = b/||b||
+  launches[KRY_K_NORMALIZE] = m + 2;
+  bytes[KRY_K_COMBINE] = (m + 1) * N;
+  launches[KRY_K_COMBINE] = 1;
+  if (g->flags & KRY_GMRES_TDP) {
+    bytes[KRY_K_PRECOND] = 5.0 * N + m * 6.0 * N;  // factor: 3 read 2 write; apply: lo,dd,ud,sol read, out written twice
+    launches[KRY_K_PRECOND] = m + 1;
+  }
+  return KRY_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Implicit-Euler step
+// ---------------------------------------------------------------------------
+static int64_t padded_to_cell(const kry_ie *ie, int ip, int jp) {
+  const int cx = ie->g.cx, cy = ie->g.cy, P = cy + 2;
+  const bool xedge = ip == 0 || ip == cx + 1, yedge = jp == 0 || jp == cy + 1;
+  if (xedge && yedge) return -1;
+  if (ip == 0) return jp - 1;
+  if (ip == cx + 1) return (int64_t)cy + (int64_t)cx * P + (jp - 1);
+  return (int64_t)cy + (int64_t)(ip - 1) * P + jp;
+}
+
+extern "C" {
+
+int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, int cx, int cy,
+                  const double *T0, const double *u0, const double *v0, double diffusion,
+                  double reynolds, double prandtl, double eckert, const int *bc_is_dirichlet, int m,
+                  int flags, kry_ie **out) {
+  if (!ctx || !out || !T0 || !u0 || !v0 || !bc_is_dirichlet) return fail(KRY_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (cx < 1 || cy < 1) return fail(KRY_ERR_INVALID, "cells_x and cells_y must be positive");
+  if ((int64_t)(cx + 2) * (cy + 2) > 2147483000LL) return fail(KRY_ERR_INVALID, "mesh too large for 32-bit cell indices");
+  HIPCHK(hipSetDevice(ctx->device));
+  kry_ie *ie = new kry_ie;
+  ie->ctx = ctx;
+  ctx_ref(ctx);
+  // Mesh::Mesh, src/mesh.cpp:11-15
+  const double min_x = c1x < c2x ? c1x : c2x, max_x = c1x < c2x ? c2x : c1x;
+  const double min_y = c1y < c2y ? c1y : c2y, max_y = c1y < c2y ? c2y : c1y;
+  if (!(min_x != max_x) || !(min_y != max_y)) {
+    delete ie;
+    ctx_unref(ctx);
+    return fail(KRY_ERR_INVALID, "degenerate domain");
+  }
+  ie->min_x = min_x;
+  ie->min_y = min_y;
+  ie->g.cx = cx;
+  ie->g.cy = cy;
+  ie->g.dx = (max_x - min_x) / (double)cx;
+  ie->g.dy = (max_y - min_y) / (double)cy;
+  ie->g.diffusion = diffusion;
+  ie->g.reynolds = reynolds;
+  ie->g.prandtl = prandtl;
+  ie->g.eckert = eckert;
+  ie->g.inv_rp = 1.0 / (reynolds * prandtl);  // include/space_disc.hpp:61
+  for (int k = 0; k < 12; k++) ie->bc.weight[k] = bc_is_dirichlet[k] ? 1.0 : 0.0;  // boundary_conds.hpp:50
+  const int P = cy + 2;
+  ie->npad = (int64_t)(cx + 2) * P;
+  ie->neq = ie->npad - 4;
+  int st = KRY_OK;
+  std::vector<double> host((size_t)ie->npad);
+  const double *src[3] = {T0, u0, v0};
+  for (int f = 0; f < 3 && st == KRY_OK; f++) {
+    // ghosts and corners start as signalling NaN, src/mesh.cpp:34-51
+    for (auto &v : host) v = kSNaN;
+    for (int i = 0; i < cx; i++)
+      for (int j = 0; j < cy; j++) host[(size_t)(i + 1) * P + (j + 1)] = src[f][(size_t)i * cy + j];
+    st = dev_alloc(&ie->fld[f], ie->npad);
+    if (st == KRY_OK && hipMemcpy(ie->fld[f], host.data(), sizeof(double) * ie->npad, hipMemcpyHostToDevice) != hipSuccess)
+      st = fail(KRY_ERR_HIP, "field upload failed");
+  }
+  for (int b = 0; b < 5 && st == KRY_OK; b++) {
+    st = dev_alloc(&ie->band[b], ie->npad);
+    if (st == KRY_OK && hipMemset(ie->band[b], 0, sizeof(double) * ie->npad) != hipSuccess) st = fail(KRY_ERR_HIP, "memset failed");
+  }
+  if (st == KRY_OK) st = dev_alloc(&ie->rhs, ie->npad);
+  if (st == KRY_OK && hipMemset(ie->rhs, 0, sizeof(double) * ie->npad) != hipSuccess) st = fail(KRY_ERR_HIP, "memset failed");
+  const int nbc = 3 * 2 * (cx + cy);
+  if (st == KRY_OK) st = dev_alloc(&ie->bcvals, nbc);
+  if (st == KRY_OK && hipHostMalloc((void **)&ie->bcvals_h, sizeof(double) * nbc) != hipSuccess) st = fail(KRY_ERR_HIP, "pinned alloc failed");
+  if (st == KRY_OK) memset(ie->bcvals_h, 0, sizeof(double) * nbc);
+  if (st == KRY_OK) st = dev_alloc(&ie->parts, kMaxParts);
+  if (st == KRY_OK) st = dev_alloc(&ie->maxd, 1);
+  if (st == KRY_OK && hipHostMalloc((void **)&ie->maxd_h, sizeof(double)) != hipSuccess) st = fail(KRY_ERR_HIP, "pinned alloc failed");
+  if (st == KRY_OK) {
+    kry_op *op = new kry_op;
+    op->ctx = ctx;
+    ctx_ref(ctx);
+    op->kind = 0;
+    op->rows = cx + 2;
+    op->cols = P;
+    op->n = ie->npad;
+    for (int b = 0; b < 5; b++) op->band[b] = ie->band[b];
+    op->own_bands = false;
+    ie->op = op;
+    if (m > 0) st = kry_gmres_create(ctx, ie->npad, m, flags, &ie->solver);
+  }
+  if (st != KRY_OK) {
+    kry_ie_destroy(ie);
+    return st;
+  }
+  *out = ie;
+  return KRY_OK;
+}
+
+void kry_ie_destroy(kry_ie *ie) {
+  if (!ie) return;
+  (void)hipSetDevice(ie->ctx->device);
+  (void)hipStreamSynchronize(ie->ctx->stream);
+  if (ie->graph_exec) (void)hipGraphExecDestroy(ie->graph_exec);
+  kry_gmres_destroy(ie->solver);
+  kry_op_destroy(ie->op);
+  for (int f = 0; f < 3; f++) (void)hipFree(ie->fld[f]);
+  for (int b = 0; b < 5; b++) (void)hipFree(ie->band[b]);
+  (void)hipFree(ie->rhs);
+  (void)hipFree(ie->bcvals);
+  (void)hipFree(ie->parts);
+  (void)hipFree(ie->maxd);
+  if (ie->bcvals_h) (void)hipHostFree(ie->bcvals_h);
+  if (ie->maxd_h) (void)hipHostFree(ie->maxd_h);
+  kry_ctx *ctx = ie->ctx;
+  delete ie;
+  ctx_unref(ctx);
+}
+
+}  // extern "C"
+
+static int ie_wait(kry_ie *ie) {
+  if (ie->pending) {
+    HIPCHK(hipStreamSynchronize(ie->ctx->stream));
+    ie->pending = false;
+  }
+  return KRY_OK;
+}
+
+static int ie_apply_bcs_async(kry_ie *ie, bool force_upload) {
+  hipStream_t st = ie->ctx->stream;
+  const int nbc = 3 * 2 * (ie->g.cx + ie->g.cy);
+  if (ie->bc_dirty || force_upload) {
+    HIPCHK(hipMemcpyAsync(ie->bcvals, ie->bcvals_h, sizeof(double) * nbc, hipMemcpyHostToDevice, st));
+    ie->bc_dirty = false;
+  }
+  launch_bc_fill(st, ie->g, ie->bc, ie->fld[0], ie->fld[1], ie->fld[2], ie->bcvals);
+  return KRY_OK;
+}
+
+static int ie_assemble_async(kry_ie *ie, double dt, bool force_upload) {
+  KCHK(ie_apply_bcs_async(ie, force_upload));
+  launch_assemble(ie->ctx->stream, ie->g, ie->bc, dt, ie->fld[0], ie->fld[1], ie->fld[2], ie->band[0],
+                  ie->band[1], ie->band[2], ie->band[3], ie->band[4], ie->rhs);
+  return launch_ok("assemble_system");
+}
+
+// everything of ImplicitEuler::timestep that runs on the device
+static int ie_step_body(kry_ie *ie, double dt, bool force_upload) {
+  hipStream_t st = ie->ctx->stream;
+  {
+    ScopedKernelTimer t(ie->ctx, KRY_K_ASSEMBLY);
+    KCHK(ie_assemble_async(ie, dt, force_upload));
+  }
+  KCHK(solve_async(ie->solver, ie->op, ie->rhs, nullptr));
+  {
+    ScopedKernelTimer t(ie->ctx, KRY_K_ASSEMBLY);
+    int np = 0;
+    launch_update_max(st, ie->g, ie->fld[0], ie->solver->vars, ie->parts, &np);
+    launch_max_final(st, ie->parts, np, ie->maxd);
+  }
+  KCHK(launch_ok("timestep"));
+  HIPCHK(hipMemcpyAsync(ie->maxd_h, ie->maxd, sizeof(double), hipMemcpyDeviceToHost, st));
+  return KRY_OK;
+}
+
+static int ie_step_async(kry_ie *ie, double dt) {
+  if (!ie->solver) return fail(KRY_ERR_STATE, "step object was created without a solver");
+  hipStream_t st = ie->ctx->stream;
+  if (!ie->use_graph) {
+    KCHK(ie_step_body(ie, dt, false));
+  } else {
+    if (!ie->graph_exec || ie->graph_dt != dt) {
+      if (ie->graph_exec) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGraphExecDestroy(ie->graph_exec));
+        ie->graph_exec = nullptr;
+      }
+      // the preconditioner work buffers must exist before capture (no allocation inside it)
+      hipGraph_t graph = nullptr;
+      const bool was_timing = ie->ctx->timing;
+      ie->ctx->timing = false;  // no event records inside a capture
+      HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = ie_step_body(ie, dt, true);
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      ie->ctx->timing = was_timing;
+      if (rc != KRY_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (e != hipSuccess) return fail(KRY_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+      e = hipGraphInstantiate(&ie->graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) return fail(KRY_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      ie->graph_dt = dt;
+    }
+    ie->bc_dirty = false;  // the graph always re-uploads the staged boundary values
+    HIPCHK(hipGraphLaunch(ie->graph_exec, st));
+  }
+  ie->pending = true;
+  ie->time += dt;  // include/time_disc.hpp:287 (after the solve: BCs were taken at the old time)
+  return KRY_OK;
+}
+
+extern "C" {
+
+int kry_ie_set_bc_values(kry_ie *ie, int field, int side, const double *vals, int len) {
+  if (!ie || !vals) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (field < 0 || field > 2 || side < 0 || side > 3) return fail(KRY_ERR_INVALID, "bad field/side");
+  const int cx = ie->g.cx, cy = ie->g.cy;
+  const int want = (side == KRY_SIDE_BOTTOM || side == KRY_SIDE_TOP) ? cx : cy;
+  if (len != want) return fail(KRY_ERR_INVALID, "side %d of a %dx%d mesh takes %d values, got %d", side, cx, cy, want, len);
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_wait(ie));  // the staging buffer may still be the source of a queued copy
+  const int per_field = 2 * (cx + cy);
+  const int off = side == KRY_SIDE_BOTTOM ? 0 : side == KRY_SIDE_TOP ? cx : side == KRY_SIDE_LEFT ? 2 * cx : 2 * cx + cy;
+  memcpy(ie->bcvals_h + (size_t)field * per_field + off, vals, sizeof(double) * (size_t)len);
+  ie->bc_dirty = true;
+  return KRY_OK;
+}
+
+int kry_ie_apply_bcs(kry_ie *ie) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_apply_bcs_async(ie, false));
+  KCHK(launch_ok("apply_bcs"));
+  ie->pending = true;
+  return KRY_OK;
+}
+
+int kry_ie_init_offdiag(kry_ie *ie) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_apply_bcs_async(ie, false));
+  launch_offdiag(ie->ctx->stream, ie->g, ie->fld[1], ie->fld[2], ie->band[0], ie->band[1], ie->band[2],
+                 ie->band[3], ie->band[4]);
+  KCHK(launch_ok("init_offdiag"));
+  ie->pending = true;
+  return KRY_OK;
+}
+
+int kry_ie_assemble_system(kry_ie *ie, double dt) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_assemble_async(ie, dt, false));
+  ie->pending = true;
+  return KRY_OK;
+}
+
+int kry_ie_timestep_async(kry_ie *ie, double dt) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  return ie_step_async(ie, dt);
+}
+
+int kry_ie_last_max_delta(kry_ie *ie, double *max_delta) {
+  if (!ie || !max_delta) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_wait(ie));
+  *max_delta = *ie->maxd_h;
+  return KRY_OK;
+}
+
+int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_step_async(ie, dt));
+  KCHK(ie_wait(ie));
+  if (max_delta) *max_delta = *ie->maxd_h;
+  return KRY_OK;
+}
+
+int kry_ie_use_graph(kry_ie *ie, int on) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  ie->use_graph = on != 0;
+  return KRY_OK;
+}
+
+double kry_ie_time(const kry_ie *ie) { return ie ? ie->time : 0.0; }
+int64_t kry_ie_num_eqns(const kry_ie *ie) { return ie ? ie->neq : 0; }
+kry_gmres *kry_ie_solver(kry_ie *ie) { return ie ? ie->solver : nullptr; }
+kry_op *kry_ie_operator(kry_ie *ie) { return ie ? ie->op : nullptr; }
+const double *kry_ie_rhs_device(kry_ie *ie) { return ie ? ie->rhs : nullptr; }
+
+int kry_ie_get_field(kry_ie *ie, int field, double *out_padded) {
+  if (!ie || !out_padded) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (field < 0 || field > 2) return fail(KRY_ERR_INVALID, "bad field");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  HIPCHK(hipMemcpyAsync(out_padded, ie->fld[field], sizeof(double) * ie->npad, hipMemcpyDeviceToHost, ie->ctx->stream));
+  HIPCHK(hipStreamSynchronize(ie->ctx->stream));
+  ie->pending = false;
+  return KRY_OK;
+}
+
+int kry_ie_get_bands(kry_ie *ie, double *out5) {
+  if (!ie || !out5) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  for (int b = 0; b < 5; b++)
+    HIPCHK(hipMemcpyAsync(out5 + (size_t)b * ie->npad, ie->band[b], sizeof(double) * ie->npad, hipMemcpyDeviceToHost, ie->ctx->stream));
+  HIPCHK(hipStreamSynchronize(ie->ctx->stream));
+  ie->pending = false;
+  return KRY_OK;
+}
+
+static int compact_download(kry_ie *ie, const double *dev, double *out) {
+  std::vector<double> host((size_t)ie->npad);
+  HIPCHK(hipMemcpyAsync(host.data(), dev, sizeof(double) * ie->npad, hipMemcpyDeviceToHost, ie->ctx->stream));
+  HIPCHK(hipStreamSynchronize(ie->ctx->stream));
+  ie->pending = false;
+  const int P = ie->g.cy + 2;
+  for (int ip = 0; ip < ie->g.cx + 2; ip++)
+    for (int jp = 0; jp < P; jp++) {
+      const int64_t c = padded_to_cell(ie, ip, jp);
+      if (c >= 0) out[c] = host[(size_t)ip * P + jp];
+    }
+  return KRY_OK;
+}
+
+int kry_ie_get_rhs(kry_ie *ie, double *out) {
+  if (!ie || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  return compact_download(ie, ie->rhs, out);
+}
+
+int kry_ie_get_delta(kry_ie *ie, double *out) {
+  if (!ie || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!ie->solver) return fail(KRY_ERR_STATE, "no solver");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  return compact_download(ie, ie->solver->vars, out);
+}
+
+int kry_ie_get_dense_system(kry_ie *ie, double *out) {
+  if (!ie || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  std::vector<double> bands((size_t)5 * ie->npad);
+  KCHK(kry_ie_get_bands(ie, bands.data()));
+  const int64_t N = ie->neq;
+  const int P = ie->g.cy + 2, R = ie->g.cx + 2;
+  memset(out, 0, sizeof(double) * (size_t)N * (size_t)N);
+  const int di[5] = {-1, 0, 0, 0, 1}, dj[5] = {0, -1, 0, 1, 0};
+  for (int ip = 0; ip < R; ip++)
+    for (int jp = 0; jp < P; jp++) {
+      const int64_t r = padded_to_cell(ie, ip, jp);
+      if (r < 0) continue;
+      for (int b = 0; b < 5; b++) {
+        const int ni = ip + di[b], nj = jp + dj[b];
+        if (ni < 0 || ni >= R || nj < 0 || nj >= P) continue;
+        const int64_t c = padded_to_cell(ie, ni, nj);
+        if (c < 0) continue;
+        const double v = bands[(size_t)b * ie->npad + (size_t)ip * P + jp];
+        if (v != 0.0) out[r * N + c] = v;
+      }
+    }
+  return KRY_OK;
+}
+
+}  // extern "C"

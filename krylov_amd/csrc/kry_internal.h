@@ -1,0 +1,87 @@
+// Internal declarations shared by the kernel and API translation units.
+#ifndef KRY_INTERNAL_H_
+#define KRY_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "krylov_amd.h"
+
+namespace kry {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
+constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups
+constexpr int kMaxParts = 2048;    // partial sums per reduction buffer
+constexpr int kMaxM = 256;         // largest Krylov dimension supported
+
+// Five coefficient bands of a stencil operator on a rows x cols padded grid.
+struct Bands {
+  const double *w, *s, *c, *n, *e;
+};
+
+// ---- launchers (all asynchronous on `st`) ---------------------------------
+int grid_for(int64_t items);
+
+// part[b] = sum over block b of x[k]^2
+void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, int *nparts);
+// nrm = sqrt(sum(part)); dst = src / nrm; *out = nrm
+void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
+                       int nparts, int64_t n, double *out);
+
+// y = A x (stencil); optionally part[b] = partial <y, vdot>
+void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
+                         double *y, const double *vdot, double *part, int *nparts);
+void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
+                     int64_t n, const double *x, double *y, const double *vdot, double *part,
+                     int *nparts);
+
+// h = sum(part_in); *hout = h; w -= h * vprev; part_out = partial <w, vcur>
+// (vcur == nullptr: partial <w, w> instead)
+void launch_mgs_step(hipStream_t st, double *w, const double *vprev, const double *vcur,
+                     const double *part_in, int np_in, double *part_out, int *np_out,
+                     double *hout, int64_t n);
+
+// y = argmin ||beta e1 - H y|| through the normal equations and an un-pivoted
+// Doolittle LU, in the reference's loop order.  work: 3*m*m + 2*m doubles.
+void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,
+                        double *work);
+// x[k] = sum_i y[i] * V[i*ld + k], accumulated in order i = 0..m-1 from 0.0
+void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m,
+                    double *x, int64_t n);
+
+// Tridiagonal preconditioner made of independent lines of length L.
+void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const double *up,
+                       double *dd, double *ud, int64_t nlines, int64_t L);
+void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const double *ud,
+                      const double *sol, double *out, int64_t nlines, int64_t L);
+// lo/di/up[k] = A(k,k-1), A(k,k), A(k,k+1) of a CSR matrix (0 where absent)
+void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col,
+                            const double *val, int64_t n, double *lo, double *di, double *up);
+
+void launch_fill(hipStream_t st, double *x, double v, int64_t n);
+
+// ---- implicit-Euler assembly ------------------------------------------------
+struct IeGeom {
+  int cx, cy;
+  double dx, dy;
+  double diffusion, reynolds, prandtl, eckert, inv_rp;
+};
+struct IeBc {
+  double weight[12];  // [field*4 + side]
+};
+
+void launch_bc_fill(hipStream_t st, const IeGeom &g, const IeBc &bc, double *T, double *u,
+                    double *v, const double *bcvals);
+void launch_offdiag(hipStream_t st, const IeGeom &g, const double *u, const double *v, double *bw,
+                    double *bs, double *bc, double *bn, double *be);
+void launch_assemble(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,
+                     const double *u, const double *v, double *bw, double *bs, double *bcn,
+                     double *bn, double *be, double *rhs);
+// T += delta on interior cells; part = per-block max |delta| (NaN sticky)
+void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double *delta,
+                       double *part, int *nparts);
+void launch_max_final(hipStream_t st, const double *part, int nparts, double *out);
+
+}  // namespace kry
+
+#endif  // KRY_INTERNAL_H_

@@ -1,0 +1,742 @@
+// HIP kernels (gfx950) for the implicit-Euler / GMRES path.
+//
+// The whole path is HBM-bound fp64 streaming: no MFMA.  Design rules used here
+//  * 256-thread workgroups (4 wave64), at most 2048 of them, grid-stride loops;
+//  * 16-byte (double2) loads and stores wherever alignment allows;
+//  * reductions: per-lane accumulators -> wave64 shuffle -> LDS -> one partial
+//    per workgroup in a scratch array.  The consumer kernel of a scalar sums
+//    the partials itself, in a fixed order that is the same in every
+//    workgroup, so results are deterministic, no atomics or fences are needed
+//    and the host never reads a scalar inside a GMRES cycle;
+//  * this file is compiled with -ffp-contract=off: element-wise arithmetic
+//    (stencil row sums, w -= h v, x += y v, assembly) is rounded exactly like
+//    the reference's scalar C++; fma() is used explicitly only inside
+//    reductions, whose summation order differs from the reference anyway.
+#include "kry_internal.h"
+
+namespace kry {
+
+int grid_for(int64_t items) {
+  int64_t b = (items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > kMaxGrid) b = kMaxGrid;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------------------
+// Reduction helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the wave total
+}
+
+// Sum over the workgroup, returned to every thread.  `s` holds kBlock/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double *s) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  double t = s[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / 64; i++) t += s[i];
+  return t;
+}
+
+// Total of a partial-sum array; every workgroup of every kernel evaluates the
+// same expression tree, so all of them obtain the same bits.
+__device__ __forceinline__ double sum_parts(const double *__restrict__ part, int np, double *s) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < np; i += kBlock) a += part[i];
+  return block_sum(a, s);
+}
+
+__device__ __forceinline__ double nan_max(double a, double b) {
+  // max that keeps a NaN once one has been seen
+  return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b);
+}
+
+// ---------------------------------------------------------------------------
+// BLAS-1 shaped kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fill(double *__restrict__ x, double v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    x[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_nrm2_part(const double *__restrict__ x, int64_t n,
+                                                       double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  const int64_t n2 = n >> 1;
+  const double2 *x2 = reinterpret_cast<const double2 *>(x);
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    const double2 v = x2[i];
+    a0 = fma(v.x, v.x, a0);
+    a1 = fma(v.y, v.y, a1);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a0 = fma(x[n - 1], x[n - 1], a0);
+  const double t = block_sum(a0 + a1, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// dst = src / sqrt(sum(part)); true division, as normalize() in include/matrix.hpp:54-60
+__global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict__ src,
+                                                        double *__restrict__ dst,
+                                                        const double *__restrict__ part, int np,
+                                                        int64_t n, double *__restrict__ out) {
+  __shared__ double s[kBlock / 64];
+  const double nrm = sqrt(sum_parts(part, np, s));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out) *out = nrm;
+  const int64_t n2 = n >> 1;
+  const double2 *s2 = reinterpret_cast<const double2 *>(src);
+  double2 *d2 = reinterpret_cast<double2 *>(dst);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    double2 v = s2[i];
+    v.x = v.x / nrm;
+    v.y = v.y / nrm;
+    d2[i] = v;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1] / nrm;
+}
+
+// One link of the modified Gram-Schmidt chain (include/solver.hpp:196-211):
+//   h = <w, v_prev> (finished here from the partials of the previous kernel)
+//   w -= h * v_prev                       (multiply, then subtract)
+//   partial <w, v_cur>   or, for the last link, partial <w, w>
+template <bool NORM>
+__global__ __launch_bounds__(kBlock) void k_mgs_step(double *__restrict__ w,
+                                                      const double *__restrict__ vprev,
+                                                      const double *__restrict__ vcur,
+                                                      const double *__restrict__ part_in, int np_in,
+                                                      double *__restrict__ part_out,
+                                                      double *__restrict__ hout, int64_t n) {
+  __shared__ double s[kBlock / 64];
+  const double h = sum_parts(part_in, np_in, s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hout = h;
+  const int64_t n2 = n >> 1;
+  double2 *w2 = reinterpret_cast<double2 *>(w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(vprev);
+  const double2 *c2 = reinterpret_cast<const double2 *>(vcur);
+  double a0 = 0.0, a1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // two independent 16-byte streams per lane per trip
+  for (; i + stride < n2; i += 2 * stride) {
+    double2 wa = w2[i], wb = w2[i + stride];
+    const double2 pa = p2[i], pb = p2[i + stride];
+    double2 ca, cb;
+    if (!NORM) {
+      ca = c2[i];
+      cb = c2[i + stride];
+    }
+    wa.x = wa.x - h * pa.x;
+    wa.y = wa.y - h * pa.y;
+    wb.x = wb.x - h * pb.x;
+    wb.y = wb.y - h * pb.y;
+    w2[i] = wa;
+    w2[i + stride] = wb;
+    if (NORM) {
+      ca = wa;
+      cb = wb;
+    }
+    a0 = fma(wa.x, ca.x, a0);
+    a1 = fma(wa.y, ca.y, a1);
+    a0 = fma(wb.x, cb.x, a0);
+    a1 = fma(wb.y, cb.y, a1);
+  }
+  if (i < n2) {
+    double2 wa = w2[i];
+    const double2 pa = p2[i];
+    wa.x = wa.x - h * pa.x;
+    wa.y = wa.y - h * pa.y;
+    w2[i] = wa;
+    const double2 ca = NORM ? wa : c2[i];
+    a0 = fma(wa.x, ca.x, a0);
+    a1 = fma(wa.y, ca.y, a1);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double wv = w[n - 1] - h * vprev[n - 1];
+    w[n - 1] = wv;
+    a0 = fma(wv, NORM ? wv : vcur[n - 1], a0);
+  }
+  const double t = block_sum(a0 + a1, s);
+  if (threadIdx.x == 0) part_out[blockIdx.x] = t;
+}
+
+// x = sum_i y_i v_i, accumulated per element in the order i = 0..m-1 starting
+// from 0.0 with a separate multiply and add (include/solver.hpp:153-159).
+__global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V, int64_t ld,
+                                                     const double *__restrict__ y, int m,
+                                                     double *__restrict__ x, int64_t n) {
+  __shared__ double ys[kMaxM];
+  for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = y[i];
+  __syncthreads();
+  const int64_t n2 = n >> 1;
+  double2 *x2 = reinterpret_cast<double2 *>(x);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll 4
+    for (int k = 0; k < m; k++) {
+      const double2 v = reinterpret_cast<const double2 *>(V + (int64_t)k * ld)[i];
+      acc.x = acc.x + ys[k] * v.x;
+      acc.y = acc.y + ys[k] * v.y;
+    }
+    x2[i] = acc;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double acc = 0.0;
+    for (int k = 0; k < m; k++) acc = acc + ys[k] * V[(int64_t)k * ld + n - 1];
+    x[n - 1] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Operator application (include/matrix.hpp:23-33 for a 5-band / CSR matrix)
+// ---------------------------------------------------------------------------
+// Row sum in ascending column order starting from +0.0:
+//   ((((0 + w x[k-P]) + s x[k-1]) + c x[k]) + n x[k+1]) + e x[k+P]
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int P,
+                                                          const double *__restrict__ x,
+                                                          double *__restrict__ y,
+                                                          const double *__restrict__ vdot,
+                                                          double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  double a0 = 0.0;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
+    const double xw = (k >= P) ? x[k - P] : 0.0;
+    const double xs = (k >= 1) ? x[k - 1] : 0.0;
+    const double xc = x[k];
+    const double xn = (k + 1 < n) ? x[k + 1] : 0.0;
+    const double xe = (k + P < n) ? x[k + P] : 0.0;
+    double acc = 0.0;
+    acc = acc + b.w[k] * xw;
+    acc = acc + b.s[k] * xs;
+    acc = acc + b.c[k] * xc;
+    acc = acc + b.n[k] * xn;
+    acc = acc + b.e[k] * xe;
+    y[k] = acc;
+    if (DOT) a0 = fma(acc, vdot[k], a0);
+  }
+  if (DOT) {
+    const double t = block_sum(a0, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+  }
+}
+
+// Vectorised form for even P and even n: every lane owns two consecutive
+// unknowns, all band / centre / +-P accesses are aligned 16-byte loads.
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, int P,
+                                                             const double *__restrict__ x,
+                                                             double *__restrict__ y,
+                                                             const double *__restrict__ vdot,
+                                                             double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  const int64_t n2 = n >> 1;
+  const int64_t P2 = P >> 1;
+  const double2 *x2 = reinterpret_cast<const double2 *>(x);
+  const double2 *bw = reinterpret_cast<const double2 *>(b.w);
+  const double2 *bs = reinterpret_cast<const double2 *>(b.s);
+  const double2 *bc = reinterpret_cast<const double2 *>(b.c);
+  const double2 *bn = reinterpret_cast<const double2 *>(b.n);
+  const double2 *be = reinterpret_cast<const double2 *>(b.e);
+  const double2 *v2 = reinterpret_cast<const double2 *>(vdot);
+  double2 *y2 = reinterpret_cast<double2 *>(y);
+  const double2 zero = make_double2(0.0, 0.0);
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t k = 2 * i;
+    const double2 xc = x2[i];
+    const double2 xw = (i >= P2) ? x2[i - P2] : zero;
+    const double2 xe = (i + P2 < n2) ? x2[i + P2] : zero;
+    const double xm1 = (k >= 1) ? x[k - 1] : 0.0;
+    const double xp2 = (k + 2 < n) ? x[k + 2] : 0.0;
+    const double2 cw = bw[i], cs = bs[i], cc = bc[i], cn = bn[i], ce = be[i];
+    double r0 = 0.0, r1 = 0.0;
+    r0 = r0 + cw.x * xw.x;
+    r1 = r1 + cw.y * xw.y;
+    r0 = r0 + cs.x * xm1;
+    r1 = r1 + cs.y * xc.x;
+    r0 = r0 + cc.x * xc.x;
+    r1 = r1 + cc.y * xc.y;
+    r0 = r0 + cn.x * xc.y;
+    r1 = r1 + cn.y * xp2;
+    r0 = r0 + ce.x * xe.x;
+    r1 = r1 + ce.y * xe.y;
+    y2[i] = make_double2(r0, r1);
+    if (DOT) {
+      const double2 vv = v2[i];
+      a0 = fma(r0, vv.x, a0);
+      a1 = fma(r1, vv.y, a1);
+    }
+  }
+  if (DOT) {
+    const double t = block_sum(a0 + a1, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+  }
+}
+
+// CSR, one row per lane, stored entries in ascending column order.
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ col,
+                                                      const double *__restrict__ val, int64_t n,
+                                                      const double *__restrict__ x,
+                                                      double *__restrict__ y,
+                                                      const double *__restrict__ vdot,
+                                                      double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  double a0 = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+    double acc = 0.0;
+    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) acc = acc + val[p] * x[col[p]];
+    y[r] = acc;
+    if (DOT) a0 = fma(acc, vdot[r], a0);
+  }
+  if (DOT) {
+    const double t = block_sum(a0, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Reduced (m x m) least-squares solve, include/solver.hpp:142-151 with
+// LUSolver::lu_decomp (:58-96) and LUSolver::solve (:34-56).  One workgroup;
+// every matrix entry is produced by exactly the reference's sequence of
+// multiplies, subtracts and divides, entries of one elimination step are
+// spread over the lanes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_small_solve(const double *__restrict__ H,
+                                                         const double *__restrict__ beta_p, int m,
+                                                         double *__restrict__ y,
+                                                         double *__restrict__ work) {
+  double *sys = work;
+  double *l = work + (size_t)m * m;
+  double *u = work + 2 * (size_t)m * m;
+  double *rhs = work + 3 * (size_t)m * m;
+  double *partial = rhs + m;
+  const int tid = threadIdx.x;
+  const double beta = *beta_p;
+  for (int e = tid; e < m * m; e += kBlock) {
+    const int i = e / m, j = e % m;
+    double acc = 0.0;
+    for (int k = 0; k < m + 1; k++) acc = acc + H[k * m + i] * H[k * m + j];
+    sys[e] = acc;
+    l[e] = 0.0;
+    u[e] = 0.0;
+  }
+  for (int i = tid; i < m; i += kBlock) rhs[i] = beta * H[i];
+  __syncthreads();
+  for (int k = 0; k < m; k++) {
+    // row k of u (the diagonal entry first; l(k,k) = 1)
+    for (int j = k + tid; j < m; j += kBlock) {
+      double v = sys[k * m + j];
+      for (int i = 0; i < k; i++) v = v - l[k * m + i] * u[i * m + j];
+      v = v / 1.0;
+      u[k * m + j] = v;
+    }
+    if (tid == 0) l[k * m + k] = 1.0;
+    __syncthreads();
+    const double ukk = u[k * m + k];
+    for (int j = k + 1 + tid; j < m; j += kBlock) {
+      double v = sys[j * m + k];
+      for (int i = 0; i < k; i++) v = v - l[j * m + i] * u[i * m + k];
+      v = v / ukk;
+      l[j * m + k] = v;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int i = 0; i < m; i++) {
+      double v = rhs[i];
+      for (int j = 0; j < i; j++) v = v - l[i * m + j] * partial[j];
+      v = v / l[i * m + i];
+      partial[i] = v;
+    }
+    for (int i = m - 1; i >= 0; i--) {
+      double v = partial[i];
+      for (int j = i + 1; j < m; j++) v = v - u[i * m + j] * y[j];
+      v = v / u[i * m + i];
+      y[i] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tridiagonal preconditioner (include/solver.hpp:246-273, :295-314).
+// The matrix is a set of independent lines of length L (for the stencil
+// operator: one padded grid row each, couplings between rows are exact zeros
+// in the reference's numbering), each solved by the Thomas recurrences of the
+// reference in the same order.  The pivots do not depend on the right-hand
+// side, so they are computed once per assembled matrix.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tdp_factor(const double *__restrict__ lo,
+                                                        const double *__restrict__ di,
+                                                        const double *__restrict__ up,
+                                                        double *__restrict__ dd,
+                                                        double *__restrict__ ud, int64_t nlines,
+                                                        int64_t L) {
+  const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (line >= nlines) return;
+  const int64_t b = line * L;
+  double diag = di[b];
+  double uprev = up[b] / diag;
+  dd[b] = diag;
+  ud[b] = uprev;
+  for (int64_t j = 1; j < L; j++) {
+    diag = di[b + j] - uprev * lo[b + j];
+    uprev = up[b + j] / diag;
+    dd[b + j] = diag;
+    ud[b + j] = uprev;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tdp_apply(const double *__restrict__ lo,
+                                                       const double *__restrict__ dd,
+                                                       const double *__restrict__ ud,
+                                                       const double *__restrict__ sol,
+                                                       double *__restrict__ out, int64_t nlines,
+                                                       int64_t L) {
+  const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (line >= nlines) return;
+  const int64_t b = line * L;
+  double prev = sol[b] / dd[b];
+  out[b] = prev;
+  for (int64_t j = 1; j < L; j++) {
+    prev = (sol[b + j] - prev * lo[b + j]) / dd[b + j];
+    out[b + j] = prev;
+  }
+  for (int64_t j = L - 2; j >= 0; j--) {
+    prev = out[b + j] - prev * ud[b + j];
+    out[b + j] = prev;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tdp_extract_csr(const int64_t *__restrict__ rowptr,
+                                                             const int32_t *__restrict__ col,
+                                                             const double *__restrict__ val,
+                                                             int64_t n, double *__restrict__ lo,
+                                                             double *__restrict__ di,
+                                                             double *__restrict__ up) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+    double a = 0.0, d = 0.0, c = 0.0;
+    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+      const int64_t cc = col[p];
+      if (cc == r - 1) a = val[p];
+      if (cc == r) d = val[p];
+      if (cc == r + 1) c = val[p];
+    }
+    lo[r] = a;
+    di[r] = d;
+    up[r] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Implicit-Euler assembly
+// ---------------------------------------------------------------------------
+// BoundaryCondition::ghost_cell, include/boundary_conds.hpp:62-66
+__device__ __forceinline__ double ghost_cell(double bndry, double bc, double size, double weight) {
+  return (2.0 * bc - bndry) * weight + (size * bc + bndry) * (1.0 - weight);
+}
+
+// All twelve ghost fills of TimeDisc::apply_bcs (include/time_disc.hpp:146-163)
+// in one launch: each reads interior cells only and writes its own ghost
+// strip, so their order is immaterial.  View wiring as in the TimeDisc
+// constructor (:51-134): left conditions read the RIGHT boundary column.
+// bcvals layout per field: [bottom cx][top cx][left cy][right cy].
+__global__ __launch_bounds__(kBlock) void k_bc_fill(IeGeom g, IeBc bc, double *__restrict__ T,
+                                                     double *__restrict__ u, double *__restrict__ v,
+                                                     const double *__restrict__ bcvals) {
+  const int per_field = 2 * (g.cx + g.cy);
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 3 * per_field) return;
+  const int f = t / per_field;
+  int r = t % per_field;
+  double *F = f == 0 ? T : (f == 1 ? u : v);
+  const int P = g.cy + 2;
+  const double bcv = bcvals[(size_t)f * per_field + r];
+#define FAT(i, j) F[(size_t)((i) + 1) * P + ((j) + 1)]
+  if (r < g.cx) {  // bottom
+    const int i = r;
+    FAT(i, -1) = ghost_cell(FAT(i, 0), bcv, g.dy, bc.weight[f * 4 + KRY_SIDE_BOTTOM]);
+    return;
+  }
+  r -= g.cx;
+  if (r < g.cx) {  // top
+    const int i = r;
+    FAT(i, g.cy) = ghost_cell(FAT(i, g.cy - 1), bcv, g.dy, bc.weight[f * 4 + KRY_SIDE_TOP]);
+    return;
+  }
+  r -= g.cx;
+  if (r < g.cy) {  // left ghost column, fed from the right boundary column
+    const int j = r;
+    FAT(-1, j) = ghost_cell(FAT(g.cx - 1, j), bcv, g.dx, bc.weight[f * 4 + KRY_SIDE_LEFT]);
+    return;
+  }
+  r -= g.cy;
+  {
+    const int j = r;
+    FAT(g.cx, j) = ghost_cell(FAT(g.cx - 1, j), bcv, g.dx, bc.weight[f * 4 + KRY_SIDE_RIGHT]);
+  }
+#undef FAT
+}
+
+// Off-diagonal bands, include/time_disc.hpp:249-274 with
+// SecondOrderCentered::Dx_m1/Dx_p1/Dy_m1/Dy_p1 (include/space_disc.hpp:83-113).
+// Everything else is cleared; corner entries get a unit diagonal so that the
+// padded operator stays non-singular (their vector entries are always 0).
+__global__ __launch_bounds__(kBlock) void k_offdiag(IeGeom g, const double *__restrict__ u,
+                                                     const double *__restrict__ v,
+                                                     double *__restrict__ bw, double *__restrict__ bs,
+                                                     double *__restrict__ bc, double *__restrict__ bn,
+                                                     double *__restrict__ be) {
+  const int P = g.cy + 2;
+  const int64_t npad = (int64_t)(g.cx + 2) * P;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < npad; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = (int)(k / P), jp = (int)(k % P);
+    const bool interior = ip >= 1 && ip <= g.cx && jp >= 1 && jp <= g.cy;
+    const bool corner = (ip == 0 || ip == g.cx + 1) && (jp == 0 || jp == g.cy + 1);
+    double w = 0.0, s = 0.0, n = 0.0, e = 0.0;
+    if (interior) {
+      const double kx = g.diffusion * g.inv_rp / g.dx;
+      const double ky = g.diffusion * g.inv_rp / g.dy;
+      s = (-v[k - 1] / 2.0 - ky) / g.dy;
+      n = (v[k + 1] / 2.0 - ky) / g.dy;
+      w = (-u[k - P] / 2.0 - kx) / g.dx;
+      e = (u[k + P] / 2.0 - kx) / g.dx;
+    }
+    bw[k] = w;
+    bs[k] = s;
+    bn[k] = n;
+    be[k] = e;
+    bc[k] = corner ? 1.0 : 0.0;
+  }
+}
+
+// ImplicitEuler::assemble_system after the ghost fill, include/time_disc.hpp:294-337:
+// interior diagonal Dx_0 + Dy_0 + 1/dt, right-hand side flux_integral +
+// source_fd (include/space_disc.hpp:19-44, :116-179), ghost rows
+// (rhs 0, inner coefficient 1, diagonal 2w-1; the right ghost column takes the
+// LEFT temperature condition's term, :335-336).
+__global__ __launch_bounds__(kBlock) void k_assemble(IeGeom g, IeBc bc, double dt,
+                                                      const double *__restrict__ T,
+                                                      const double *__restrict__ u,
+                                                      const double *__restrict__ v,
+                                                      double *__restrict__ bw, double *__restrict__ bs,
+                                                      double *__restrict__ bcn, double *__restrict__ bn,
+                                                      double *__restrict__ be,
+                                                      double *__restrict__ rhs) {
+  const int P = g.cy + 2;
+  const int64_t npad = (int64_t)(g.cx + 2) * P;
+  const double dx = g.dx, dy = g.dy;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < npad; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = (int)(k / P), jp = (int)(k % P);
+    const bool xin = ip >= 1 && ip <= g.cx, yin = jp >= 1 && jp <= g.cy;
+    if (xin && yin) {
+      const double Dx0 = 2.0 * g.diffusion * g.inv_rp / (dx * dx);
+      const double Dy0 = 2.0 * g.diffusion * g.inv_rp / (dy * dy);
+      bcn[k] = Dx0 + Dy0 + 1.0 / dt;
+      const double Tc = T[k], Tw = T[k - P], Te = T[k + P], Ts = T[k - 1], Tn = T[k + 1];
+      const double uc = u[k], uw = u[k - P], ue = u[k + P], us = u[k - 1], un = u[k + 1];
+      const double vc = v[k], vw = v[k - P], ve = v[k + P], vs = v[k - 1], vn = v[k + 1];
+      // flux_integral
+      const double fx_hi = (Tc * uc + Te * ue) / 2.0;  // uT_x_flux(i, j)
+      const double fx_lo = (Tw * uw + Tc * uc) / 2.0;  // uT_x_flux(i-1, j)
+      const double fy_hi = (Tc * vc + Tn * vn) / 2.0;  // vT_y_flux(i, j)
+      const double fy_lo = (Ts * vs + Tc * vc) / 2.0;  // vT_y_flux(i, j-1)
+      const double x_deriv = (fx_hi - fx_lo) / dx;
+      const double y_deriv = (fy_hi - fy_lo) / dy;
+      const double x2_deriv = ((Te - Tc) / dx - (Tc - Tw) / dx) / dx;
+      const double y2_deriv = ((Tn - Tc) / dy - (Tc - Ts) / dy) / dy;
+      const double lapl = (x2_deriv + y2_deriv) * g.inv_rp;
+      const double flux = (-x_deriv - y_deriv) + g.diffusion * lapl;
+      // source_fd
+      const double u_dx = (ue - uw) / (2.0 * dx);
+      const double v_dy = (vn - vs) / (2.0 * dy);
+      const double u_dy = (un - us) / (2.0 * dy);
+      const double v_dx = (ve - vw) / (2.0 * dx);
+      const double cross = u_dy + v_dx;
+      const double src = g.eckert / g.reynolds * (2.0 * (u_dx * u_dx + v_dy * v_dy) + cross * cross);
+      rhs[k] = flux + src;
+    } else {
+      rhs[k] = 0.0;
+      if (xin && jp == g.cy + 1) {  // top ghost: inner neighbour is k-1
+        bs[k] = 1.0;
+        bcn[k] = 2.0 * bc.weight[KRY_SIDE_TOP] - 1.0;
+      } else if (xin && jp == 0) {  // bottom ghost: inner neighbour is k+1
+        bn[k] = 1.0;
+        bcn[k] = 2.0 * bc.weight[KRY_SIDE_BOTTOM] - 1.0;
+      } else if (yin && ip == 0) {  // left ghost: inner neighbour is k+P
+        be[k] = 1.0;
+        bcn[k] = 2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0;
+      } else if (yin && ip == g.cx + 1) {  // right ghost: inner neighbour is k-P
+        bw[k] = 1.0;
+        bcn[k] = 2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0;
+      }
+    }
+  }
+}
+
+// State update of ImplicitEuler::timestep, include/time_disc.hpp:281-286:
+// T += delta and max |delta| over interior cells only.
+__global__ __launch_bounds__(kBlock) void k_update_max(IeGeom g, double *__restrict__ T,
+                                                        const double *__restrict__ delta,
+                                                        double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  const int P = g.cy + 2;
+  const int64_t npad = (int64_t)(g.cx + 2) * P;
+  double m = 0.0;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < npad; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = (int)(k / P), jp = (int)(k % P);
+    if (ip >= 1 && ip <= g.cx && jp >= 1 && jp <= g.cy) {
+      const double d = delta[k];
+      T[k] = T[k] + d;
+      m = nan_max(fabs(d), m);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = nan_max(m, __shfl_down(m, off, 64));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s[wv] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = s[0];
+    for (int i = 1; i < kBlock / 64; i++) t = nan_max(t, s[i]);
+    part[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_max_final(const double *__restrict__ part, int np,
+                                                   double *__restrict__ out) {
+  double m = 0.0;
+  for (int i = threadIdx.x; i < np; i += 64) m = nan_max(m, part[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = nan_max(m, __shfl_down(m, off, 64));
+  if (threadIdx.x == 0) *out = m;
+}
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+void launch_fill(hipStream_t st, double *x, double v, int64_t n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, x, v, n);
+}
+
+void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, int *nparts) {
+  const int g = grid_for((n + 1) / 2);
+  *nparts = g;
+  hipLaunchKernelGGL(k_nrm2_part, dim3(g), dim3(kBlock), 0, st, x, n, part);
+}
+
+void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
+                       int nparts, int64_t n, double *out) {
+  const int g = grid_for((n + 1) / 2);
+  hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out);
+}
+
+void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
+                         double *y, const double *vdot, double *part, int *nparts) {
+  const bool vec = (cols % 2 == 0) && (n % 2 == 0);
+  const int g = grid_for(vec ? n / 2 : n);
+  if (nparts) *nparts = g;
+  if (vec) {
+    if (vdot)
+      hipLaunchKernelGGL(k_spmv_stencil_v2<true>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
+    else
+      hipLaunchKernelGGL(k_spmv_stencil_v2<false>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
+  } else {
+    if (vdot)
+      hipLaunchKernelGGL(k_spmv_stencil<true>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
+    else
+      hipLaunchKernelGGL(k_spmv_stencil<false>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
+  }
+}
+
+void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
+                     int64_t n, const double *x, double *y, const double *vdot, double *part,
+                     int *nparts) {
+  const int g = grid_for(n);
+  if (nparts) *nparts = g;
+  if (vdot)
+    hipLaunchKernelGGL(k_spmv_csr<true>, dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, vdot, part);
+  else
+    hipLaunchKernelGGL(k_spmv_csr<false>, dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, vdot, part);
+}
+
+void launch_mgs_step(hipStream_t st, double *w, const double *vprev, const double *vcur,
+                     const double *part_in, int np_in, double *part_out, int *np_out,
+                     double *hout, int64_t n) {
+  const int g = grid_for((n + 1) / 2);
+  *np_out = g;
+  if (vcur)
+    hipLaunchKernelGGL(k_mgs_step<false>, dim3(g), dim3(kBlock), 0, st, w, vprev, vcur, part_in, np_in, part_out, hout, n);
+  else
+    hipLaunchKernelGGL(k_mgs_step<true>, dim3(g), dim3(kBlock), 0, st, w, vprev, vcur, part_in, np_in, part_out, hout, n);
+}
+
+void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,
+                        double *work) {
+  hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(kBlock), 0, st, H, beta, m, y, work);
+}
+
+void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x,
+                    int64_t n) {
+  const int g = grid_for((n + 1) / 2);
+  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n);
+}
+
+void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const double *up,
+                       double *dd, double *ud, int64_t nlines, int64_t L) {
+  const int g = (int)((nlines + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_tdp_factor, dim3(g), dim3(kBlock), 0, st, lo, di, up, dd, ud, nlines, L);
+}
+
+void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const double *ud,
+                      const double *sol, double *out, int64_t nlines, int64_t L) {
+  const int g = (int)((nlines + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_tdp_apply, dim3(g), dim3(kBlock), 0, st, lo, dd, ud, sol, out, nlines, L);
+}
+
+void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col,
+                            const double *val, int64_t n, double *lo, double *di, double *up) {
+  hipLaunchKernelGGL(k_tdp_extract_csr, dim3(grid_for(n)), dim3(kBlock), 0, st, rowptr, col, val, n, lo, di, up);
+}
+
+void launch_bc_fill(hipStream_t st, const IeGeom &g, const IeBc &bc, double *T, double *u,
+                    double *v, const double *bcvals) {
+  const int total = 3 * 2 * (g.cx + g.cy);
+  hipLaunchKernelGGL(k_bc_fill, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g, bc, T, u, v, bcvals);
+}
+
+void launch_offdiag(hipStream_t st, const IeGeom &g, const double *u, const double *v, double *bw,
+                    double *bs, double *bc, double *bn, double *be) {
+  const int64_t npad = (int64_t)(g.cx + 2) * (g.cy + 2);
+  hipLaunchKernelGGL(k_offdiag, dim3(grid_for(npad)), dim3(kBlock), 0, st, g, u, v, bw, bs, bc, bn, be);
+}
+
+void launch_assemble(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,
+                     const double *u, const double *v, double *bw, double *bs, double *bcn,
+                     double *bn, double *be, double *rhs) {
+  const int64_t npad = (int64_t)(g.cx + 2) * (g.cy + 2);
+  hipLaunchKernelGGL(k_assemble, dim3(grid_for(npad)), dim3(kBlock), 0, st, g, bc, dt, T, u, v, bw, bs, bcn, bn, be, rhs);
+}
+
+void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double *delta,
+                       double *part, int *nparts) {
+  const int64_t npad = (int64_t)(g.cx + 2) * (g.cy + 2);
+  const int gr = grid_for(npad);
+  *nparts = gr;
+  hipLaunchKernelGGL(k_update_max, dim3(gr), dim3(kBlock), 0, st, g, T, delta, part);
+}
+
+void launch_max_final(hipStream_t st, const double *part, int nparts, double *out) {
+  hipLaunchKernelGGL(k_max_final, dim3(1), dim3(64), 0, st, part, nparts, out);
+}
+
+}  // namespace kry

@@ -1,0 +1,426 @@
+"""Parity of the HIP path (through the C ABI) against the CPU restatement and
+against the reference's own known-answer tests.  Bars:
+  * integer / index work, operator applies, boundary fills and assembly
+    (element-wise fp64 in the reference's operation order): bit-exact;
+  * anything downstream of a dot product or norm (summation order differs
+    from the reference's sequential loop): relative 2-norm error <= 1e-10,
+    the tolerance of the north-star requirement, with tighter bars where the
+    reference's own tests state them.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from krylov_amd import capi, host, problems
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RTOL = 1e-10  # relative solution error allowed against the CPU reference
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def simple_test(size):
+    A = np.zeros((size, size))
+    b = np.zeros(size)
+    b[4], b[5], b[6] = 1.0, 5.0, 1.0
+    for i in range(size):
+        A[i, i] = -2.0
+        if i < size - 1:
+            A[i + 1, i] = 1.0
+            A[i, i + 1] = 1.0
+    return A, b
+
+
+EXPECTED_X = np.array([5.0, 10.0, 15.0, 20.0, 25.0, 199.0 / 7.0, 24.0, 18.0, 12.0, 6.0]) * (-7.0 / 11.0)
+
+
+# ---- the reference's known-answer tests, run on the device --------------------
+
+def test_product_matrix_vector(ctx):
+    """TEST(product, matrix), src/test.cpp:688-705: exact."""
+    m = np.array([[1.0, -4.0, -2.0], [1.0, 2.0, 4.0], [0.0, 0.0, 0.0]])
+    op = host.Operator.dense(ctx, m)
+    assert np.array_equal(op.apply(np.array([2.0, 4.0, 5.0])), np.array([-24.0, 30.0, 0.0]))
+
+
+def test_arnoldi_gmres(ctx):
+    """TEST(arnoldi, gmres), src/test.cpp:247-291, same tolerances."""
+    A, b = simple_test(10)
+    op = host.Operator.dense(ctx, A)
+    g = host.GMRESSolver(ctx, 10, 10)
+    assert np.all(np.isnan(g.prev_result()))  # include/solver.hpp:16-18
+    g.initial_subspace(b)
+    assert np.max(np.abs(g.subspace_vector(0) - b * math.sqrt(3) / 9.0)) <= 1e-15
+    h10 = g.add_arnoldi(op)
+    assert abs(h10 - 2.0 * math.sqrt(278) / 27.0) <= 1e-15
+    e1 = np.array([0.0, 0.0, 0.0, 27.0, 115.0, -46.0, 115.0, 27.0, 0.0, 0.0])
+    assert np.max(np.abs(g.subspace_vector(1) - math.sqrt(3.0 * 278) / 5004.0 * e1)) <= 1e-15
+    h21 = g.add_arnoldi(op)
+    assert abs(h21 - 3.0 * math.sqrt(2373.0) / 139.0) <= 1e-15
+    e2 = np.array([0.0, 0.0, 278.0, 1265.0, -275.0, 110.0, -275.0, 1265.0, 278.0, 0.0])
+    assert np.max(np.abs(g.subspace_vector(2) / (math.sqrt(278.0 * 791.0) / 879592.0) - e2)) <= 2e-12
+    x = g.solve(op, b)
+    assert np.max(np.abs(x - EXPECTED_X)) <= 1e-12
+    assert np.array_equal(g.prev_result(), x)
+
+
+def known_preconditioner_system():
+    A = np.zeros((10, 10))
+    for i in range(10):
+        A[i, i] = -2.0
+        if i < 9:
+            A[i, i + 1] = 1.0
+        if i > 0:
+            A[i, i - 1] = 1.0
+    A[0, 0] = -1.0
+    return A, np.array([0.0, 0.0, 0.0, 0.0, 1.0, 5.0, 1.0, 0.0, 0.0, 0.0])
+
+
+def test_known_preconditioner_gmres(ctx):
+    """TEST(known_preconditioner, gmres), src/test.cpp:469-520."""
+    A, b = known_preconditioner_system()
+    g = host.GMRESSolver(ctx, 10, 3, tdp=True)
+    P = g.assemble_preconditioner(host.Operator.dense(ctx, A))
+    assert np.isnan(P[0, 0]) and np.isnan(P[9, 2])
+    assert P[0, 1] == -1.0 and P[0, 2] == 1.0
+    for i in range(1, 9):
+        assert tuple(P[i]) == (1.0, -2.0, 1.0)
+    assert P[9, 0] == 1.0 and P[9, 1] == -2.0
+    A[0, 0] = -2.0
+    op = host.Operator.dense(ctx, A)
+    beta = g.initial_subspace(b)
+    assert abs(beta - math.sqrt(3) * 3.0) <= 1e-15
+    h10 = g.add_arnoldi(op)
+    assert abs(g.hessenberg(0, 0) - 1.0) <= 1e-15
+    assert abs(g.hessenberg(1, 0) - h10) <= 1e-15
+    assert abs(h10 - 35.0 * math.sqrt(3) / 9.0) <= 1e-15
+    v2 = g.subspace_vector(1)
+    assert abs(v2[0] - 1.0) <= 1e-15 and np.max(np.abs(v2[1:])) <= 2e-15
+    h21 = g.add_arnoldi(op)
+    assert abs(g.hessenberg(0, 1)) <= 1e-15
+    assert abs(g.hessenberg(1, 1) - 11.0) <= 1e-15
+    assert abs(g.hessenberg(2, 1)) <= 1e-15 and abs(h21) <= 1e-15
+
+
+def test_sparse_tridiag_through_preconditioner(ctx, oracle):
+    """TEST(sparsetridiag, solvers), src/test.cpp:222-245: the Thomas solve is
+    reached through the preconditioned Arnoldi step; with A = tridiagonal the
+    first step gives w = A M^-1 v0 = v0, i.e. H(0,0) = 1 and H(1,0) ~ 0."""
+    A, b = simple_test(10)
+    op = host.Operator.dense(ctx, A)
+    g = host.GMRESSolver(ctx, 10, 2, tdp=True)
+    g.assemble_preconditioner(op)
+    g.initial_subspace(b)
+    h10 = g.add_arnoldi(op)
+    assert abs(g.hessenberg(0, 0) - 1.0) <= 4e-15 and abs(h10) <= 1e-14
+    # fixed (opt-in) right preconditioning returns the true solution M^-1 u
+    gf = host.GMRESSolver(ctx, 10, 1, tdp=True, fixed_preconditioning=True)
+    x = gf.solve(op, b)
+    assert np.max(np.abs(x - EXPECTED_X)) <= 1e-13
+
+
+def test_preconditioner_gmres_random(ctx, oracle):
+    """TEST(preconditioner, gmres), src/test.cpp:429-467, seeded; also compared
+    with the restatement."""
+    rng = np.random.default_rng(11)
+    for _ in range(5):
+        A = rng.uniform(-100.0, 100.0, (10, 10))
+        b = rng.uniform(-100.0, 100.0, 10)
+        op = host.Operator.dense(ctx, A)
+        g = host.GMRESSolver(ctx, 10, 2, tdp=True)
+        P = g.assemble_preconditioner(op)
+        ref = oracle.Gmres(10, 2, tdp=True)
+        oop = oracle.Op.dense(A)
+        Pref = ref.assemble_preconditioner(oop)
+        assert np.array_equal(P[1:, 0], Pref[1:, 0]) and np.array_equal(P[:, 1], Pref[:, 1])
+        assert np.array_equal(P[:-1, 2], Pref[:-1, 2])
+        g.initial_subspace(b)
+        ref.initial_subspace(b)
+        g.add_arnoldi(op)
+        ref.add_arnoldi(oop)
+        v1, v2 = g.subspace_vector(0), g.subspace_vector(1)
+        assert abs(v1 @ v1 - 1.0) <= 1e-15 and abs(v2 @ v2 - 1.0) <= 4e-15
+        assert rel(v2, ref.subspace_vector(1)) <= 1e-12
+
+
+def test_rejects_bad_arguments(ctx):
+    A, b = simple_test(10)
+    op = host.Operator.dense(ctx, A)
+    with pytest.raises(capi.KrylovError):
+        host.GMRESSolver(ctx, 10, 0)
+    g = host.GMRESSolver(ctx, 12, 3)
+    with pytest.raises(capi.KrylovError):
+        g.solve(op, np.zeros(12))  # size mismatch
+    g = host.GMRESSolver(ctx, 10, 2)
+    with pytest.raises(capi.KrylovError):
+        g.add_arnoldi(op)  # before initial_subspace
+    g.initial_subspace(b)
+    g.add_arnoldi(op)
+    g.add_arnoldi(op)
+    with pytest.raises(capi.KrylovError):
+        g.add_arnoldi(op)  # subspace full
+    with pytest.raises(capi.KrylovError):
+        host.Operator.csr(ctx, [0, 2], [1, 0], [1.0, 2.0])  # columns not ascending
+
+
+# ---- operator apply: bit-exact --------------------------------------------------
+
+@pytest.mark.parametrize("cx,cy", [(38, 18), (7, 5), (3, 1), (1, 4), (33, 17), (64, 64)])
+def test_stencil_apply_bit_exact(ctx, oracle, cx, cy):
+    """Device 5-band apply == dense/CSR row sum of include/matrix.hpp:23-33,
+    for even and odd padded row lengths (vectorised and scalar kernels)."""
+    ref = oracle.ImplicitEuler(**problems.prob1(cx, cy), m=2)
+    ref.assemble_system(0.25)
+    dev = host.ImplicitEuler(ctx, **problems.prob1(cx, cy), m=2)
+    dev.assemble_system(0.25)
+    rowptr, col, val = ref.csr()
+    op = dev.operator()
+    rng = np.random.default_rng(cx * 100 + cy)
+    for _ in range(3):
+        xp = np.zeros((cx + 2, cy + 2))
+        xp[1:-1, :] = rng.uniform(-1.0, 1.0, (cx, cy + 2))
+        xp[0, 1:-1] = rng.uniform(-1.0, 1.0, cy)
+        xp[-1, 1:-1] = rng.uniform(-1.0, 1.0, cy)
+        y = op.apply(xp.reshape(-1)).reshape(cx + 2, cy + 2)
+        want = oracle.csr_matvec(rowptr, col, val, dev.compact(xp))
+        assert np.array_equal(dev.compact(y), want)
+        assert y[0, 0] == 0 and y[0, -1] == 0 and y[-1, 0] == 0 and y[-1, -1] == 0
+
+
+def test_csr_apply_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(5)
+    n = 301
+    dense = np.where(rng.uniform(size=(n, n)) < 0.03, rng.uniform(-2.0, 2.0, (n, n)), 0.0)
+    x = rng.uniform(-1.0, 1.0, n)
+    op = host.Operator.dense(ctx, dense)
+    assert np.array_equal(op.apply(x), oracle.dense_matvec(dense, x))
+
+
+# ---- boundary fill and assembly: bit-exact ---------------------------------------
+
+CASES = [("prob1", problems.prob1, (38, 18)), ("prob1", problems.prob1, (9, 7)),
+         ("rough", problems.rough_field, (18, 8)), ("rough", problems.rough_field, (62, 62)),
+         ("timedep", problems.time_dependent, (12, 10)), ("siso", lambda a, b: problems.s_iso(a, b), (40, 24)),
+         ("prob1", problems.prob1, (1, 1)), ("prob1", problems.prob1, (2, 5))]
+
+
+@pytest.mark.parametrize("name,make,shape", CASES)
+def test_ghost_fill_and_assembly_bit_exact(ctx, oracle, name, make, shape):
+    """apply_bcs (include/time_disc.hpp:146-163), the frozen off-diagonals
+    (:249-274) and assemble_system (:291-339): fields, matrix and right-hand
+    side equal the restatement bit for bit, NaN corners included."""
+    ref = oracle.ImplicitEuler(**make(*shape), m=2)
+    dev = host.ImplicitEuler(ctx, **make(*shape), m=2)
+    assert dev.n == ref.n
+    for f in range(3):
+        assert np.array_equal(dev.field(f), ref.field(f), equal_nan=True)
+    for dt in (0.25, 0.1):
+        ref.assemble_system(dt)
+        dev.assemble_system(dt)
+        assert np.array_equal(dev.sol_vec(), ref.sol_vec())
+        if ref.n <= 4100:
+            assert np.array_equal(dev.dense_system(), ref.dense_system())
+    b = dev.bands()
+    for k in range(5):
+        for c in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+            assert b[k][c] == (1.0 if k == 2 else 0.0)
+
+
+# ---- GMRES against the restatement -------------------------------------------------
+
+@pytest.mark.parametrize("m,tdp", [(2, False), (10, False), (30, False), (50, False), (10, True), (30, True)])
+def test_gmres_cycle_matches_reference(ctx, oracle, m, tdp):
+    """One fixed-m cycle on the assembled prob1 system: Hessenberg matrix,
+    basis and solution against the CPU restatement."""
+    ref = oracle.ImplicitEuler(**problems.prob1(), m=m, tdp=tdp)
+    dev = host.ImplicitEuler(ctx, **problems.prob1(), m=m, tdp=tdp)
+    ref.assemble_system(0.25)
+    dev.assemble_system(0.25)
+    b = ref.sol_vec()
+    x_ref = ref.solver().solve(ref.op(), b)
+    bp = np.zeros((dev.cx + 2, dev.cy + 2))
+    bp[0, 1:-1] = b[:dev.cy]
+    bp[1:-1, :] = b[dev.cy:-dev.cy].reshape(dev.cx, dev.cy + 2)
+    bp[-1, 1:-1] = b[-dev.cy:]
+    assert np.array_equal(dev.compact(bp), b)
+    g = dev.solver()
+    x = dev.compact(g.solve(dev.operator(), bp.reshape(-1)))
+    H, Href = g.hessenberg_matrix(), ref.solver().hessenberg_matrix()
+    # The solution is the quantity with a parity bar.  Individual Arnoldi
+    # vectors / Hessenberg columns are only compared while they are well
+    # determined: once the Krylov space has captured b to rounding level, later
+    # vectors are orthonormalised rounding noise in both implementations.
+    assert rel(x, x_ref) <= RTOL
+    early = min(m, 3 if tdp else 8)  # the preconditioned space converges within a few steps
+    assert np.max(np.abs(H[:, :early] - Href[:, :early])) <= 1e-10 * np.max(np.abs(Href))
+    for k in (0, 1, early):
+        assert rel(dev.compact(g.subspace_vector(k)), ref.solver().subspace_vector(k)) <= 1e-9
+    # basis stays orthonormal to rounding level
+    V = np.stack([g.subspace_vector(k) for k in range(m + 1)])
+    assert np.max(np.abs(V @ V.T - np.eye(m + 1))) <= 1e-9
+
+
+def test_gmres_general_matrix(ctx, oracle):
+    """Stand-alone GMRESSolver<m>.solve(Matrix, Vector) on a dense non-symmetric
+    matrix (src/bindpy.cpp:669-707): CSR path."""
+    rng = np.random.default_rng(17)
+    n = 200
+    A = np.eye(n) * 4.0 + np.where(rng.uniform(size=(n, n)) < 0.05, rng.uniform(-1, 1, (n, n)), 0.0)
+    b = rng.uniform(-1.0, 1.0, n)
+    for m, tdp in ((20, False), (20, True)):
+        x_ref = oracle.Gmres(n, m, tdp).solve(oracle.Op.dense(A), b)
+        x = host.GMRESSolver(ctx, n, m, tdp).solve(host.Operator.dense(ctx, A), b)
+        assert rel(x, x_ref) <= RTOL
+
+
+def test_gmres_scaling_is_exact(ctx):
+    """Scaling b by a power of two scales every intermediate exactly, so the
+    answer must scale bit for bit (a size-independent property)."""
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(96, 64), m=12)
+    dev.assemble_system(0.25)
+    rng = np.random.default_rng(1)
+    bp = np.zeros((98, 66))
+    bp[1:-1, 1:-1] = rng.uniform(-1, 1, (96, 64))
+    g, op = dev.solver(), dev.operator()
+    x1 = g.solve(op, bp.reshape(-1)).copy()
+    x4 = g.solve(op, 4.0 * bp.reshape(-1))
+    assert np.array_equal(4.0 * x1, x4)
+    x1b = g.solve(op, bp.reshape(-1))
+    assert np.array_equal(x1, x1b)  # deterministic reductions
+
+
+# ---- whole time steps ------------------------------------------------------------------
+
+def _golden():
+    with open(os.path.join(HERE, "golden", "prob1_reference_runs.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_recorded_reference_runs_first_steps(ctx, idx):
+    """First five steps of the prob1 replay against the values printed by the
+    unmodified reference (plain GMRES converging, preconditioned GMRES
+    diverging exactly as the reference does)."""
+    run = _golden()["runs"][idx]
+    dev = host.ImplicitEuler(ctx, **problems.prob1(run["cx"], run["cy"]), m=run["m"],
+                             tdp=run["solver"] == "GMRESTDPSolver")
+    for k in range(5):
+        d = dev.timestep(run["dt"])
+        want = run["max_delta"][str(k)]
+        assert abs(d - want) <= 1e-9 * abs(want), (k, d, want)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_prob1_replay_to_steady_state(ctx, oracle, graph):
+    """Headless replay of scripts/prob1.py:90-98 with GMRESSolver<10>: same
+    number of steps (147), same final field as the reference."""
+    run = _golden()["runs"][2]
+    dev = host.ImplicitEuler(ctx, **problems.prob1(), m=10, use_graph=graph)
+    ref = oracle.ImplicitEuler(**problems.prob1(), m=10)
+    d, steps = float("inf"), 0
+    while d > 1e-9 and steps < 400:
+        d = dev.timestep(0.25)
+        dr = ref.timestep(0.25)
+        steps += 1
+        assert abs(d - dr) <= 1e-9 * abs(dr) + 1e-13, (steps, d, dr)  # |T| ~ 1: floor at rounding level
+    assert steps == run["steps_to_1e-9"]
+    assert abs(dev.cur_time() - 0.25 * steps) == 0.0
+    T = dev.field(0)
+    assert abs(np.sum(T[1:-1, 1:-1]) - run["sum_T_interior"]) <= 1e-10 * run["sum_T_interior"]
+    assert rel(T[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]) <= RTOL
+    assert np.isnan(T[0, 0]) and np.isnan(T[-1, -1])
+
+
+def test_preconditioned_divergence_reaches_nan(ctx):
+    """The default solver of scripts/prob1.py diverges; the step keeps
+    returning finite growth and finally NaN, which ends prob1's loop."""
+    dev = host.ImplicitEuler(ctx, **problems.prob1(), m=10, tdp=True)
+    run = _golden()["runs"][0]
+    seq = [dev.timestep(0.25) for _ in range(90)]
+    assert abs(seq[50] - run["max_delta"]["50"]) <= 1e-6 * run["max_delta"]["50"]
+    first_nan = next(i for i, v in enumerate(seq) if math.isnan(v)) + 1
+    assert abs(first_nan - run["first_nan_step_1based"]) <= 1
+
+
+@pytest.mark.parametrize("name,make,shape,m,tdp", [
+    ("timedep", problems.time_dependent, (12, 10), 8, False),
+    ("timedep", problems.time_dependent, (12, 10), 8, True),
+    ("rough", problems.rough_field, (18, 8), 40, False),
+    ("siso", lambda a, b: problems.s_iso(a, b), (64, 48), 30, False),
+    ("siso", lambda a, b: problems.s_iso(a, b), (33, 65), 20, True),
+    ("tiny", problems.prob1, (1, 1), 2, False),
+    ("tiny", problems.prob1, (2, 3), 4, True),
+])
+def test_timesteps_match_reference(ctx, oracle, name, make, shape, m, tdp):
+    """Several steps with time-dependent boundary values, odd sizes, both
+    solvers: max|delta| per step, delta vector and temperature field."""
+    ref = oracle.ImplicitEuler(**make(*shape), m=m, tdp=tdp)
+    dev = host.ImplicitEuler(ctx, **make(*shape), m=m, tdp=tdp)
+    for step in range(4):
+        dr = ref.timestep(0.25)
+        d = dev.timestep(0.25)
+        if not (math.isfinite(dr) and dr < 1e100):
+            break
+        assert abs(d - dr) <= 1e-8 * abs(dr), (step, d, dr)
+        assert rel(dev.delta(), ref.delta()) <= 1e-8
+        assert rel(dev.field(0)[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]) <= 1e-8
+        assert dev.cur_time() == ref.cur_time()
+    # ghost cells of the velocity fields follow the moving boundary values exactly
+    for f in (1, 2):
+        assert np.array_equal(dev.field(f), ref.field(f), equal_nan=True)
+
+
+def test_config1_one_step_2048_gmres30_vs_cpu(ctx, oracle):
+    """BASELINE config 2 at reduced cost: one implicit step of GMRES(30) on a
+    1024 x 1024 synthetic mesh against the CPU restatement."""
+    n = 1024
+    prob = problems.s_iso(n)
+    ref = oracle.ImplicitEuler(**prob, m=30)
+    dev = host.ImplicitEuler(ctx, **prob, m=30, bc_time_dependent=False)
+    dr = ref.timestep(0.25)
+    d = dev.timestep(0.25)
+    assert abs(d - dr) <= RTOL * abs(dr)
+    assert rel(dev.delta(), ref.delta()) <= RTOL
+    assert rel(dev.field(0)[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]) <= RTOL
+
+
+@pytest.mark.parametrize("n,m", [(2048, 30), (8192, 50)])
+def test_full_size_properties(ctx, n, m):
+    """BASELINE configs 2 and 3 at full size through size-independent
+    properties: orthonormality of sampled basis vectors, the Arnoldi relation,
+    and least-squares optimality of the returned combination (its true
+    residual equals the residual of the small least-squares problem)."""
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(n), m=m, bc_time_dependent=False)
+    dev.assemble_system(0.25)
+    g, op = dev.solver(), dev.operator()
+    g.solve_device(op, dev.rhs_device(), None)
+    x = g.prev_result()
+    H = g.hessenberg_matrix()
+    assert np.all(np.isfinite(H)) and np.all(np.isfinite(x))
+    idx = [0, 1, m // 2, m - 1, m]
+    vs = [g.subspace_vector(i) for i in idx]
+    for a in range(len(idx)):
+        for c in range(a, len(idx)):
+            dotp = float(vs[a] @ vs[c])
+            # unit length to rounding; modified Gram-Schmidt loses orthogonality
+            # in proportion to the convergence already reached, in the reference too
+            assert abs(dotp - (1.0 if a == c else 0.0)) <= (1e-12 if a == c else 1e-6), (idx[a], idx[c], dotp)
+    # Arnoldi relation, first column: A v_0 = H(0,0) v_0 + H(1,0) v_1
+    assert rel(op.apply(vs[0]), H[0, 0] * vs[0] + H[1, 0] * vs[1]) <= 1e-12
+    del vs
+    bp = dev.expand(dev.sol_vec())
+    beta = float(np.linalg.norm(bp))
+    r = bp - op.apply(x)
+    e1 = np.zeros(m + 1)
+    e1[0] = beta
+    yls = np.linalg.lstsq(H, e1, rcond=None)[0]
+    ls_res = float(np.linalg.norm(e1 - H @ yls))
+    assert abs(float(np.linalg.norm(r)) - ls_res) <= 1e-8 * beta
+    assert float(np.linalg.norm(r)) < 1e-2 * beta
