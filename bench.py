@@ -13,8 +13,8 @@ N > 1 the same mesh is split into row blocks, one rank per GPU (strong
 scaling), with halo exchange and all-reduced dot products over RCCL.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel (one Gram-Schmidt link, 32 B per unknown)
-                 timed live with HIP events on the stream it runs on;
+  roofline     : the dominant kernel (one full Gram-Schmidt sweep, 80 B per
+                 unknown) timed live with HIP events on the stream it runs on;
   cpu_baseline : the single-threaded CPU restatement (oracle/) timed on this
                  box's host cores on a bounded sample of the same workload.
 """
@@ -117,9 +117,11 @@ def main():
                          "alg_bytes_per_launch": per_launch,
                          "gbps": round(per_launch / (avg_ms * 1e-3) / 1e9, 1) if per_launch else None}
     roofline = None
-    if "mgs_link" in kernels:
-        k = kernels["mgs_link"]
-        per_launch = 32.0 * N  # read w, v_prev, v_cur; write w: 4 x 8 B per unknown
+    if "mgs_block_full" in kernels:
+        k = kernels["mgs_block_full"]
+        # one full Gram-Schmidt sweep: w read + written, 4 basis vectors applied,
+        # 4 basis vectors dotted: 10 x 8 B per unknown
+        per_launch = 80.0 * N
         achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -127,10 +129,10 @@ def main():
             try:
                 tj = json.load(open(tfile))
                 if tj.get("mesh") == n_side:
-                    traffic = tj.get("mgs_link_hbm_bytes_per_launch")
+                    traffic = tj.get("mgs_block_full_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_mgs_step<false> (one modified-Gram-Schmidt link)",
+        roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,2> (Gram-Schmidt sweep: 4 projections applied + 4 dots)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],

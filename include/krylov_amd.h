@@ -131,20 +131,28 @@ int kry_gmres_hessenberg_matrix(kry_gmres *g, double *out_host);
 int kry_gmres_prev_result(kry_gmres *g, double *out_host);
 /* Device pointer to the n-entry result vector. */
 const double *kry_gmres_result_device(kry_gmres *g);
+/* Number of modified-Gram-Schmidt links fused into one sweep over the work
+ * vector, 1..4 (default 4).  1 is the reference's plain chain, one link per
+ * sweep (include/solver.hpp:198-207); larger groups take the group's dot
+ * products in one pass and recover the same coefficients through the group's
+ * Gram entries, h_k = <w, v_k> - sum_{a<k} h_a <v_a, v_k>. */
+int kry_gmres_set_mgs_block(kry_gmres *g, int k);
+int kry_gmres_get_mgs_block(const kry_gmres *g);
 int64_t kry_gmres_size(const kry_gmres *g);
 int kry_gmres_iterations(const kry_gmres *g);
 /* Kernel-level timing hooks for the benchmark: algorithmic bytes moved by the
  * kernels of one full cycle, per class (see kry_kernel_class). */
 enum kry_kernel_class {
   KRY_K_SPMV = 0,      /* operator apply fused with <w, v_0>                    */
-  KRY_K_MGS = 1,       /* Gram-Schmidt link: w -= h v_prev, <w, v_cur>          */
-  KRY_K_MGS_LAST = 2,  /* last link of a step: w -= h v_j, <w, w>               */
-  KRY_K_NORMALIZE = 3, /* v = w / ||w|| (and v_0 = b / ||b||)                   */
-  KRY_K_COMBINE = 4,   /* x = sum y_i v_i                                       */
-  KRY_K_PRECOND = 5,   /* tridiagonal line solves                               */
-  KRY_K_ASSEMBLY = 6,  /* ghost fill, right-hand side, state update             */
-  KRY_K_OTHER = 7,     /* reduced m x m solve                                   */
-  KRY_K_COUNT = 8
+  KRY_K_MGS = 1,       /* full Gram-Schmidt sweep: 4 projections applied, 4 dots taken */
+  KRY_K_MGS_PART = 2,  /* Gram-Schmidt sweep over a shorter group               */
+  KRY_K_MGS_LAST = 3,  /* last sweep of a step: projections applied, <w, w>     */
+  KRY_K_NORMALIZE = 4, /* v = w / ||w|| (and v_0 = b / ||b||)                   */
+  KRY_K_COMBINE = 5,   /* x = sum y_i v_i                                       */
+  KRY_K_PRECOND = 6,   /* tridiagonal line solves                               */
+  KRY_K_ASSEMBLY = 7,  /* ghost fill, right-hand side, state update             */
+  KRY_K_OTHER = 8,     /* reduced m x m solve                                   */
+  KRY_K_COUNT = 9
 };
 int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY_K_COUNT],
                           int launches[KRY_K_COUNT]);

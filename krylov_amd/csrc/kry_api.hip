@@ -112,13 +112,14 @@ struct kry_gmres {
   kry_ctx *ctx = nullptr;
   int64_t n = 0, ld = 0;
   int m = 0, flags = 0;
+  int kblock = kMgsBlock;  // Gram-Schmidt links fused per sweep (1 = the plain chain)
   int nvec = 0;  // subspace.size()
   double *V = nullptr;      // (m+1) x ld
   double *H = nullptr;      // (m+1) x m
   double *w = nullptr;      // Arnoldi work vector
   double *z = nullptr;      // preconditioned vector
   double *vars = nullptr;   // Solver::vars
-  double *parts = nullptr;  // 2 x kMaxParts
+  double *parts = nullptr;  // 2 x kMaxRed x kMaxParts (ping-pong partial sums)
   double *beta = nullptr;   // 1
   double *y = nullptr;      // m
   double *work = nullptr;   // 3 m^2 + 2 m
@@ -377,15 +378,15 @@ int64_t kry_op_size(const kry_op *op) { return op ? op->n : 0; }
 
 }  // extern "C"
 
-// y = A x; optionally the partial sums of <y, vdot>
-static void op_apply_async(kry_op *op, const double *x, double *y, const double *vdot, double *part,
-                           int *nparts) {
+// y = A x; with kc > 0 also the partial sums of the first Gram-Schmidt group
+static void op_apply_async(kry_op *op, const double *x, double *y, int kc, const double *cbase,
+                           int64_t ld, double *part, int *nparts) {
   hipStream_t st = op->ctx->stream;
   if (op->kind == 0) {
     Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
-    launch_spmv_stencil(st, b, op->n, op->cols, x, y, vdot, part, nparts);
+    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts);
   } else {
-    launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, vdot, part, nparts);
+    launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, kc, cbase, ld, part, nparts);
   }
 }
 
@@ -395,7 +396,7 @@ int kry_op_apply_device(kry_op *op, const double *x_dev, double *y_dev) {
   if (!op || !x_dev || !y_dev) return fail(KRY_ERR_INVALID, "NULL argument");
   if (x_dev == y_dev) return fail(KRY_ERR_INVALID, "x and y must not alias");
   HIPCHK(hipSetDevice(op->ctx->device));
-  op_apply_async(op, x_dev, y_dev, nullptr, nullptr, nullptr);
+  op_apply_async(op, x_dev, y_dev, 0, nullptr, 0, nullptr, nullptr);
   return launch_ok("kry_op_apply_device");
 }
 
@@ -406,7 +407,7 @@ int kry_op_apply(kry_op *op, const double *x_host, double *y_host) {
   if (!op->ty) KCHK(dev_alloc(&op->ty, op->n));
   hipStream_t st = op->ctx->stream;
   HIPCHK(hipMemcpyAsync(op->tx, x_host, sizeof(double) * op->n, hipMemcpyHostToDevice, st));
-  op_apply_async(op, op->tx, op->ty, nullptr, nullptr, nullptr);
+  op_apply_async(op, op->tx, op->ty, 0, nullptr, 0, nullptr, nullptr);
   KCHK(launch_ok("kry_op_apply"));
   HIPCHK(hipMemcpyAsync(y_host, op->ty, sizeof(double) * op->n, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -435,12 +436,16 @@ int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out)
   g->ld = (n + 31) / 32 * 32;  // 256-byte multiple: every basis vector is 16-byte aligned
   g->m = m;
   g->flags = flags;
+  if (const char *e = getenv("KRY_MGS_BLOCK")) {  // experimentation knob, same range as the setter
+    const int k = atoi(e);
+    if (k >= 1 && k <= kMgsBlock) g->kblock = k;
+  }
   int st = KRY_OK;
   if (st == KRY_OK) st = dev_alloc(&g->V, (int64_t)(m + 1) * g->ld);
   if (st == KRY_OK) st = dev_alloc(&g->H, (int64_t)(m + 1) * m);
   if (st == KRY_OK) st = dev_alloc(&g->w, g->ld);
   if (st == KRY_OK) st = dev_alloc(&g->vars, g->ld);
-  if (st == KRY_OK) st = dev_alloc(&g->parts, 2 * kMaxParts);
+  if (st == KRY_OK) st = dev_alloc(&g->parts, 2 * (int64_t)kMaxRed * kMaxParts);
   if (st == KRY_OK) st = dev_alloc(&g->beta, 1);
   if (st == KRY_OK) st = dev_alloc(&g->y, m);
   if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 2 * m);
@@ -483,6 +488,15 @@ void kry_gmres_destroy(kry_gmres *g) {
   delete g;
   ctx_unref(ctx);
 }
+
+int kry_gmres_set_mgs_block(kry_gmres *g, int k) {
+  if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (k < 1 || k > kMgsBlock) return fail(KRY_ERR_INVALID, "block size must be in [1, %d]", kMgsBlock);
+  g->kblock = k;
+  return KRY_OK;
+}
+
+int kry_gmres_get_mgs_block(const kry_gmres *g) { return g ? g->kblock : 0; }
 
 int64_t kry_gmres_size(const kry_gmres *g) { return g ? g->n : 0; }
 int kry_gmres_iterations(const kry_gmres *g) { return g ? g->m : 0; }
@@ -546,7 +560,7 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   if (j >= g->m) return fail(KRY_ERR_STATE, "subspace is full (%d vectors for num_iters = %d)", g->nvec, g->m);
   hipStream_t st = g->ctx->stream;
   const int64_t n = g->n;
-  double *part[2] = {g->parts, g->parts + kMaxParts};
+  double *part[2] = {g->parts, g->parts + (int64_t)kMaxRed * kMaxParts};
   int np[2] = {0, 0};
   const double *src = basis(g, j);
   if (g->flags & KRY_GMRES_TDP) {
@@ -555,24 +569,33 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
     launch_tdp_apply(st, g->lo, g->dd, g->ud, src, g->z, g->nlines, g->L);
     src = g->z;
   }
+  // Orthogonalise against v_0..v_j in groups of up to K vectors (modified
+  // Gram-Schmidt order is kept: group after group, vector after vector).
+  const int K = g->kblock;
+  const int nv = j + 1;
+  int ps = 0, kp = nv < K ? nv : K;  // previous group: start, size
   {
-    // w = A v_j and the partial sums of <w, v_0>
+    // w = A v_j fused with the dots of the first group
     ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
-    op_apply_async(op, src, g->w, basis(g, 0), part[0], &np[0]);
+    op_apply_async(op, src, g->w, kp, basis(g, 0), g->ld, part[0], &np[0]);
   }
-  for (int i = 1; i <= j; i++) {
-    ScopedKernelTimer t(g->ctx, KRY_K_MGS);
-    launch_mgs_step(st, g->w, basis(g, i - 1), basis(g, i), part[(i - 1) & 1], np[(i - 1) & 1],
-                    part[i & 1], &np[i & 1], g->H + (int64_t)(i - 1) * g->m + j, n);
+  int cur = 1;
+  for (int cs = kp; cs < nv; cs += K, cur++) {
+    const int kc = nv - cs < K ? nv - cs : K;
+    ScopedKernelTimer t(g->ctx, (kp == kMgsBlock && kc == kMgsBlock) ? KRY_K_MGS : KRY_K_MGS_PART);
+    launch_mgs_block(st, kp, kc, g->w, basis(g, ps), basis(g, cs), g->ld, part[(cur - 1) & 1],
+                     np[(cur - 1) & 1], part[cur & 1], &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
+    ps = cs;
+    kp = kc;
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-    launch_mgs_step(st, g->w, basis(g, j), nullptr, part[j & 1], np[j & 1], part[(j + 1) & 1],
-                    &np[(j + 1) & 1], g->H + (int64_t)j * g->m + j, n);
+    launch_mgs_block(st, kp, 0, g->w, basis(g, ps), nullptr, g->ld, part[(cur - 1) & 1], np[(cur - 1) & 1],
+                     part[cur & 1], &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
-    launch_scale_from(st, g->w, basis(g, j + 1), part[(j + 1) & 1], np[(j + 1) & 1], n,
+    launch_scale_from(st, g->w, basis(g, j + 1), part[cur & 1], np[cur & 1], n,
                       g->H + (int64_t)(j + 1) * g->m + j);
   }
   g->nvec++;
@@ -720,16 +743,22 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
   }
   const double N = 8.0 * (double)g->n;  // bytes of one vector
   const int m = g->m;
-  // operator apply fused with the first dot: bands/CSR + x + v_0 read, y written
-  double spmv = op->kind == 0 ? 5.0 * N + 3.0 * N
-                              : 12.0 * (double)op->nnz + 8.0 * (double)(op->n + 1) + 3.0 * N;
-  bytes[KRY_K_SPMV] = spmv * m;
-  launches[KRY_K_SPMV] = m;
-  // chain links: read w, v_prev, v_cur, write w (4N); last link of a step: 3N
+  const int K = g->kblock;
+  // bytes of the operator itself: five bands, or CSR values + indices + row pointers
+  const double opb = op->kind == 0 ? 5.0 * N : 12.0 * (double)op->nnz + 8.0 * (double)(op->n + 1);
   for (int j = 0; j < m; j++) {
-    bytes[KRY_K_MGS] += 4.0 * N * j;
-    launches[KRY_K_MGS] += j;
-    bytes[KRY_K_MGS_LAST] += 3.0 * N;
+    const int nv = j + 1;
+    int kp = nv < K ? nv : K;
+    bytes[KRY_K_SPMV] += opb + N + N + kp * N;  // operator, x read, y written, first group read
+    launches[KRY_K_SPMV] += 1;
+    for (int cs = kp; cs < nv; cs += K) {
+      const int kc = nv - cs < K ? nv - cs : K;
+      const int cls = (kp == kMgsBlock && kc == kMgsBlock) ? KRY_K_MGS : KRY_K_MGS_PART;
+      bytes[cls] += (2.0 + kp + kc) * N;  // w read + written, kp applied, kc dotted
+      launches[cls] += 1;
+      kp = kc;
+    }
+    bytes[KRY_K_MGS_LAST] += (2.0 + kp) * N;
     launches[KRY_K_MGS_LAST] += 1;
   }
   bytes[KRY_K_NORMALIZE] = 2.0 * N * m + 3.0 * N;  // m normalisations + ||b|| and v_0 = b/||b||

@@ -58,6 +58,47 @@ __device__ __forceinline__ double nan_max(double a, double b) {
   return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b);
 }
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ d2 ld_nt(const d2 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_nt(d2 v, d2 *p) { __builtin_nontemporal_store(v, p); }
+
+constexpr int nred(int k) { return k + k * (k - 1) / 2; }
+
+// Totals of NQ partial-sum arrays, evaluated by the same expression tree in
+// every workgroup: wave q % 4 reduces array q with its 64 lanes.
+template <int NQ>
+__device__ __forceinline__ void sum_parts_multi(const double *__restrict__ part, int np, double *tot /* LDS, NQ */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int q = wv; q < NQ; q += kBlock / 64) {
+    double a = 0.0;
+    for (int i = lane; i < np; i += 64) a += part[(size_t)q * kMaxParts + i];
+    a = wave_sum(a);
+    if (lane == 0) tot[q] = a;
+  }
+  __syncthreads();
+}
+
+// Block-level reduction of NQ accumulators into part[q * kMaxParts + blockIdx.x].
+template <int NQ>
+__device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? NQ : 1], double *red /* LDS NQ*4 */,
+                                                    double *__restrict__ part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const double t = wave_sum(acc[q]);
+    if (lane == 0) red[q * (kBlock / 64) + wv] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    double t = red[threadIdx.x * (kBlock / 64)];
+#pragma unroll
+    for (int i = 1; i < kBlock / 64; i++) t += red[threadIdx.x * (kBlock / 64) + i];
+    part[(size_t)threadIdx.x * kMaxParts + blockIdx.x] = t;
+  }
+}
+
+
 // ---------------------------------------------------------------------------
 // BLAS-1 shaped kernels
 // ---------------------------------------------------------------------------
@@ -70,12 +111,20 @@ __global__ __launch_bounds__(kBlock) void k_nrm2_part(const double *__restrict__
                                                        double *__restrict__ part) {
   __shared__ double s[kBlock / 64];
   const int64_t n2 = n >> 1;
-  const double2 *x2 = reinterpret_cast<const double2 *>(x);
+  const d2 *x2 = reinterpret_cast<const d2 *>(x);
   double a0 = 0.0, a1 = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-    const double2 v = x2[i];
-    a0 = fma(v.x, v.x, a0);
-    a1 = fma(v.y, v.y, a1);
+  constexpr int U = 4;
+  const int64_t tile = (int64_t)kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < n2) {
+        const d2 v = ld_nt(&x2[i]);
+        a0 = fma(v.x, v.x, a0);
+        a1 = fma(v.y, v.y, a1);
+      }
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a0 = fma(x[n - 1], x[n - 1], a0);
   const double t = block_sum(a0 + a1, s);
@@ -91,79 +140,155 @@ __global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict_
   const double nrm = sqrt(sum_parts(part, np, s));
   if (blockIdx.x == 0 && threadIdx.x == 0 && out) *out = nrm;
   const int64_t n2 = n >> 1;
-  const double2 *s2 = reinterpret_cast<const double2 *>(src);
-  double2 *d2 = reinterpret_cast<double2 *>(dst);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-    double2 v = s2[i];
-    v.x = v.x / nrm;
-    v.y = v.y / nrm;
-    d2[i] = v;
+  const d2 *s2 = reinterpret_cast<const d2 *>(src);
+  d2 *o2 = reinterpret_cast<d2 *>(dst);
+  constexpr int U = 4;
+  const int64_t tile = (int64_t)kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
+    d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < n2) v[u] = ld_nt(&s2[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < n2) {
+        d2 r;
+        r.x = v[u].x / nrm;
+        r.y = v[u].y / nrm;
+        st_nt(r, &o2[i]);
+      }
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1] / nrm;
 }
 
-// One link of the modified Gram-Schmidt chain (include/solver.hpp:196-211):
-//   h = <w, v_prev> (finished here from the partials of the previous kernel)
-//   w -= h * v_prev                       (multiply, then subtract)
-//   partial <w, v_cur>   or, for the last link, partial <w, w>
-template <bool NORM>
-__global__ __launch_bounds__(kBlock) void k_mgs_step(double *__restrict__ w,
-                                                      const double *__restrict__ vprev,
-                                                      const double *__restrict__ vcur,
-                                                      const double *__restrict__ part_in, int np_in,
-                                                      double *__restrict__ part_out,
-                                                      double *__restrict__ hout, int64_t n) {
-  __shared__ double s[kBlock / 64];
-  const double h = sum_parts(part_in, np_in, s);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *hout = h;
+// ---------------------------------------------------------------------------
+// Blocked modified Gram-Schmidt pass (include/solver.hpp:196-211).
+//
+// The reference orthogonalises w against v_0, v_1, ... one vector at a time:
+//   h_i = <w, v_i>;  w -= h_i v_i        (dot taken with the UPDATED w).
+// Every link is one sweep over w.  This kernel does up to kMgsBlock links per
+// sweep.  For a group c_0..c_{KC-1} of basis vectors it accumulates, in one
+// pass over the already-updated w,
+//     d_k  = <w, c_k>            and      g_ab = <c_a, c_b>   (a < b),
+// and the NEXT kernel (its prologue, identically in every workgroup) recovers
+// the modified-Gram-Schmidt coefficients exactly as the recurrence defines them,
+//     h_0 = d_0,  h_1 = d_1 - h_0 g_01,  h_2 = d_2 - h_0 g_02 - h_1 g_12, ...
+// (because <w - h_0 c_0, c_1> = <w, c_1> - h_0 <c_0, c_1>), then applies
+//     w -= h_0 c_0;  w -= h_1 c_1; ...   element-wise in the reference's order
+// (multiply, then subtract) while taking the dots of the following group.
+// KC = 0 with NORM: the last pass of an Arnoldi step, accumulates <w, w>.
+//
+// Partial sums: part[q * kMaxParts + workgroup], q < KC + KC (KC-1)/2 (dots
+// first, then Gram entries in (a, b) lexicographic order), or q = 0 for NORM.
+// ---------------------------------------------------------------------------
+template <int KP, int KC, bool NORM, int U>
+__global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
+                                                       const double *__restrict__ pbase,
+                                                       const double *__restrict__ cbase, int64_t ld,
+                                                       const double *__restrict__ part_in, int np_in,
+                                                       double *__restrict__ part_out,
+                                                       double *__restrict__ hout, int hstride,
+                                                       int64_t n) {
+  constexpr int NQI = nred(KP);
+  constexpr int NQO = NORM ? 1 : nred(KC);
+  __shared__ double tot[NQI];
+  __shared__ double red[NQO * (kBlock / 64)];
+  sum_parts_multi<NQI>(part_in, np_in, tot);
+  // modified Gram-Schmidt coefficients of the previous group
+  double h[KP];
+  {
+    int gq = KP;  // Gram entries follow the KP dots, (a, b) lexicographic
+    double g[KP > 1 ? KP * KP : 1];
+#pragma unroll
+    for (int a = 0; a < KP; a++)
+#pragma unroll
+      for (int b = a + 1; b < KP; b++) g[a * KP + b] = tot[gq++];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+      double v = tot[k];
+#pragma unroll
+      for (int a = 0; a < k; a++) v = v - h[a] * g[a * KP + k];
+      h[k] = v;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < KP) {
+#pragma unroll
+    for (int k = 0; k < KP; k++)
+      if ((int)threadIdx.x == k) hout[(size_t)k * hstride] = h[k];
+  }
   const int64_t n2 = n >> 1;
-  double2 *w2 = reinterpret_cast<double2 *>(w);
-  const double2 *p2 = reinterpret_cast<const double2 *>(vprev);
-  const double2 *c2 = reinterpret_cast<const double2 *>(vcur);
-  double a0 = 0.0, a1 = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  // two independent 16-byte streams per lane per trip
-  for (; i + stride < n2; i += 2 * stride) {
-    double2 wa = w2[i], wb = w2[i + stride];
-    const double2 pa = p2[i], pb = p2[i + stride];
-    double2 ca, cb;
-    if (!NORM) {
-      ca = c2[i];
-      cb = c2[i + stride];
+  d2 *w2 = reinterpret_cast<d2 *>(w);
+  double acc[NQO];
+#pragma unroll
+  for (int q = 0; q < NQO; q++) acc[q] = 0.0;
+  const int64_t tile = (int64_t)kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
+    d2 wv[U], pv[KP][U], cv[KC > 0 ? KC : 1][U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < n2) {
+        wv[u] = ld_nt(&w2[i]);
+#pragma unroll
+        for (int k = 0; k < KP; k++) pv[k][u] = ld_nt(reinterpret_cast<const d2 *>(pbase + (int64_t)k * ld) + i);
+#pragma unroll
+        for (int k = 0; k < KC; k++) cv[k][u] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)k * ld) + i);
+      }
     }
-    wa.x = wa.x - h * pa.x;
-    wa.y = wa.y - h * pa.y;
-    wb.x = wb.x - h * pb.x;
-    wb.y = wb.y - h * pb.y;
-    w2[i] = wa;
-    w2[i + stride] = wb;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < n2) {
+        d2 r = wv[u];
+#pragma unroll
+        for (int k = 0; k < KP; k++) r = r - h[k] * pv[k][u];
+        st_nt(r, &w2[i]);
+        if (NORM) {
+          acc[0] = fma(r.x, r.x, acc[0]);
+          acc[0] = fma(r.y, r.y, acc[0]);
+        } else {
+          int q = KC;
+#pragma unroll
+          for (int a = 0; a < KC; a++) {
+            acc[a] = fma(r.x, cv[a][u].x, acc[a]);
+            acc[a] = fma(r.y, cv[a][u].y, acc[a]);
+#pragma unroll
+            for (int b = a + 1; b < KC; b++) {
+              acc[q] = fma(cv[a][u].x, cv[b][u].x, acc[q]);
+              acc[q] = fma(cv[a][u].y, cv[b][u].y, acc[q]);
+              q++;
+            }
+          }
+        }
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail element
+    const int64_t e = n - 1;
+    double r = w[e];
+#pragma unroll
+    for (int k = 0; k < KP; k++) r = r - h[k] * pbase[(int64_t)k * ld + e];
+    w[e] = r;
     if (NORM) {
-      ca = wa;
-      cb = wb;
+      acc[0] = fma(r, r, acc[0]);
+    } else {
+      int q = KC;
+#pragma unroll
+      for (int a = 0; a < KC; a++) {
+        acc[a] = fma(r, cbase[(int64_t)a * ld + e], acc[a]);
+#pragma unroll
+        for (int b = a + 1; b < KC; b++) {
+          acc[q] = fma(cbase[(int64_t)a * ld + e], cbase[(int64_t)b * ld + e], acc[q]);
+          q++;
+        }
+      }
     }
-    a0 = fma(wa.x, ca.x, a0);
-    a1 = fma(wa.y, ca.y, a1);
-    a0 = fma(wb.x, cb.x, a0);
-    a1 = fma(wb.y, cb.y, a1);
   }
-  if (i < n2) {
-    double2 wa = w2[i];
-    const double2 pa = p2[i];
-    wa.x = wa.x - h * pa.x;
-    wa.y = wa.y - h * pa.y;
-    w2[i] = wa;
-    const double2 ca = NORM ? wa : c2[i];
-    a0 = fma(wa.x, ca.x, a0);
-    a1 = fma(wa.y, ca.y, a1);
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const double wv = w[n - 1] - h * vprev[n - 1];
-    w[n - 1] = wv;
-    a0 = fma(wv, NORM ? wv : vcur[n - 1], a0);
-  }
-  const double t = block_sum(a0 + a1, s);
-  if (threadIdx.x == 0) part_out[blockIdx.x] = t;
+  reduce_store_multi<NQO>(acc, red, part_out);
 }
 
 // x = sum_i y_i v_i, accumulated per element in the order i = 0..m-1 starting
@@ -175,16 +300,15 @@ __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V
   for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = y[i];
   __syncthreads();
   const int64_t n2 = n >> 1;
-  double2 *x2 = reinterpret_cast<double2 *>(x);
+  d2 *x2 = reinterpret_cast<d2 *>(x);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-    double2 acc = make_double2(0.0, 0.0);
-#pragma unroll 4
+    d2 acc = {0.0, 0.0};
+#pragma unroll 8
     for (int k = 0; k < m; k++) {
-      const double2 v = reinterpret_cast<const double2 *>(V + (int64_t)k * ld)[i];
-      acc.x = acc.x + ys[k] * v.x;
-      acc.y = acc.y + ys[k] * v.y;
+      const d2 v = ld_nt(reinterpret_cast<const d2 *>(V + (int64_t)k * ld) + i);
+      acc = acc + ys[k] * v;
     }
-    x2[i] = acc;
+    st_nt(acc, &x2[i]);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double acc = 0.0;
@@ -194,113 +318,156 @@ __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V
 }
 
 // ---------------------------------------------------------------------------
-// Operator application (include/matrix.hpp:23-33 for a 5-band / CSR matrix)
+// Operator application (include/matrix.hpp:23-33 for a 5-band / CSR matrix),
+// fused with the first Gram-Schmidt group: besides y = A x the kernels
+// accumulate <y, c_k> for KC basis vectors c_k = cbase + k*ld and the Gram
+// entries <c_a, c_b> (layout of the partial sums as in k_mgs_block).
 // ---------------------------------------------------------------------------
+template <int KC>
+__device__ __forceinline__ void accum_scalar(double r, const double *__restrict__ cbase, int64_t ld,
+                                             int64_t k, double (&acc)[KC > 0 ? nred(KC) : 1]) {
+  double c[KC > 0 ? KC : 1];
+#pragma unroll
+  for (int a = 0; a < KC; a++) c[a] = cbase[(int64_t)a * ld + k];
+  int q = KC;
+#pragma unroll
+  for (int a = 0; a < KC; a++) {
+    acc[a] = fma(r, c[a], acc[a]);
+#pragma unroll
+    for (int b = a + 1; b < KC; b++) {
+      acc[q] = fma(c[a], c[b], acc[q]);
+      q++;
+    }
+  }
+}
+
 // Row sum in ascending column order starting from +0.0:
 //   ((((0 + w x[k-P]) + s x[k-1]) + c x[k]) + n x[k+1]) + e x[k+P]
-template <bool DOT>
+template <int KC>
 __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int P,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ y,
-                                                          const double *__restrict__ vdot,
+                                                          const double *__restrict__ cbase, int64_t ld,
                                                           double *__restrict__ part) {
-  __shared__ double s[kBlock / 64];
-  double a0 = 0.0;
+  constexpr int NQ = KC > 0 ? nred(KC) : 1;
+  __shared__ double red[NQ * (kBlock / 64)];
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
     const double xw = (k >= P) ? x[k - P] : 0.0;
     const double xs = (k >= 1) ? x[k - 1] : 0.0;
     const double xc = x[k];
     const double xn = (k + 1 < n) ? x[k + 1] : 0.0;
     const double xe = (k + P < n) ? x[k + P] : 0.0;
-    double acc = 0.0;
-    acc = acc + b.w[k] * xw;
-    acc = acc + b.s[k] * xs;
-    acc = acc + b.c[k] * xc;
-    acc = acc + b.n[k] * xn;
-    acc = acc + b.e[k] * xe;
-    y[k] = acc;
-    if (DOT) a0 = fma(acc, vdot[k], a0);
+    double r = 0.0;
+    r = r + b.w[k] * xw;
+    r = r + b.s[k] * xs;
+    r = r + b.c[k] * xc;
+    r = r + b.n[k] * xn;
+    r = r + b.e[k] * xe;
+    y[k] = r;
+    if (KC > 0) accum_scalar<KC>(r, cbase, ld, k, acc);
   }
-  if (DOT) {
-    const double t = block_sum(a0, s);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
-  }
+  if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }
 
 // Vectorised form for even P and even n: every lane owns two consecutive
-// unknowns, all band / centre / +-P accesses are aligned 16-byte loads.
-template <bool DOT>
+// unknowns; band, centre and +-P accesses are aligned 16-byte loads.  Bands,
+// partners and the result are streamed non-temporally; x keeps the default
+// policy because its rows are reused by the neighbouring rows' sums.
+template <int KC>
 __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, int P,
                                                              const double *__restrict__ x,
                                                              double *__restrict__ y,
-                                                             const double *__restrict__ vdot,
+                                                             const double *__restrict__ cbase, int64_t ld,
                                                              double *__restrict__ part) {
-  __shared__ double s[kBlock / 64];
+  constexpr int NQ = KC > 0 ? nred(KC) : 1;
+  __shared__ double red[NQ * (kBlock / 64)];
   const int64_t n2 = n >> 1;
   const int64_t P2 = P >> 1;
-  const double2 *x2 = reinterpret_cast<const double2 *>(x);
-  const double2 *bw = reinterpret_cast<const double2 *>(b.w);
-  const double2 *bs = reinterpret_cast<const double2 *>(b.s);
-  const double2 *bc = reinterpret_cast<const double2 *>(b.c);
-  const double2 *bn = reinterpret_cast<const double2 *>(b.n);
-  const double2 *be = reinterpret_cast<const double2 *>(b.e);
-  const double2 *v2 = reinterpret_cast<const double2 *>(vdot);
-  double2 *y2 = reinterpret_cast<double2 *>(y);
-  const double2 zero = make_double2(0.0, 0.0);
-  double a0 = 0.0, a1 = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-    const int64_t k = 2 * i;
-    const double2 xc = x2[i];
-    const double2 xw = (i >= P2) ? x2[i - P2] : zero;
-    const double2 xe = (i + P2 < n2) ? x2[i + P2] : zero;
-    const double xm1 = (k >= 1) ? x[k - 1] : 0.0;
-    const double xp2 = (k + 2 < n) ? x[k + 2] : 0.0;
-    const double2 cw = bw[i], cs = bs[i], cc = bc[i], cn = bn[i], ce = be[i];
-    double r0 = 0.0, r1 = 0.0;
-    r0 = r0 + cw.x * xw.x;
-    r1 = r1 + cw.y * xw.y;
-    r0 = r0 + cs.x * xm1;
-    r1 = r1 + cs.y * xc.x;
-    r0 = r0 + cc.x * xc.x;
-    r1 = r1 + cc.y * xc.y;
-    r0 = r0 + cn.x * xc.y;
-    r1 = r1 + cn.y * xp2;
-    r0 = r0 + ce.x * xe.x;
-    r1 = r1 + ce.y * xe.y;
-    y2[i] = make_double2(r0, r1);
-    if (DOT) {
-      const double2 vv = v2[i];
-      a0 = fma(r0, vv.x, a0);
-      a1 = fma(r1, vv.y, a1);
+  const d2 *x2 = reinterpret_cast<const d2 *>(x);
+  const d2 *bw = reinterpret_cast<const d2 *>(b.w);
+  const d2 *bs = reinterpret_cast<const d2 *>(b.s);
+  const d2 *bc = reinterpret_cast<const d2 *>(b.c);
+  const d2 *bn = reinterpret_cast<const d2 *>(b.n);
+  const d2 *be = reinterpret_cast<const d2 *>(b.e);
+  d2 *y2 = reinterpret_cast<d2 *>(y);
+  const d2 zero = {0.0, 0.0};
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+  constexpr int U = 2;
+  const int64_t tile = (int64_t)kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < n2) {
+        const int64_t k = 2 * i;
+        const d2 xc = x2[i];
+        const d2 xw = (i >= P2) ? x2[i - P2] : zero;
+        const d2 xe = (i + P2 < n2) ? x2[i + P2] : zero;
+        const double xm1 = (k >= 1) ? x[k - 1] : 0.0;
+        const double xp2 = (k + 2 < n) ? x[k + 2] : 0.0;
+        const d2 cw = ld_nt(&bw[i]), cs = ld_nt(&bs[i]), cc = ld_nt(&bc[i]), cn = ld_nt(&bn[i]), ce = ld_nt(&be[i]);
+        d2 cv[KC > 0 ? KC : 1];
+#pragma unroll
+        for (int a = 0; a < KC; a++) cv[a] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)a * ld) + i);
+        double r0 = 0.0, r1 = 0.0;
+        r0 = r0 + cw.x * xw.x;
+        r1 = r1 + cw.y * xw.y;
+        r0 = r0 + cs.x * xm1;
+        r1 = r1 + cs.y * xc.x;
+        r0 = r0 + cc.x * xc.x;
+        r1 = r1 + cc.y * xc.y;
+        r0 = r0 + cn.x * xc.y;
+        r1 = r1 + cn.y * xp2;
+        r0 = r0 + ce.x * xe.x;
+        r1 = r1 + ce.y * xe.y;
+        d2 r = {r0, r1};
+        st_nt(r, &y2[i]);
+        if (KC > 0) {
+          int q = KC;
+#pragma unroll
+          for (int a = 0; a < KC; a++) {
+            acc[a] = fma(r0, cv[a].x, acc[a]);
+            acc[a] = fma(r1, cv[a].y, acc[a]);
+#pragma unroll
+            for (int c2 = a + 1; c2 < KC; c2++) {
+              acc[q] = fma(cv[a].x, cv[c2].x, acc[q]);
+              acc[q] = fma(cv[a].y, cv[c2].y, acc[q]);
+              q++;
+            }
+          }
+        }
+      }
     }
   }
-  if (DOT) {
-    const double t = block_sum(a0 + a1, s);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
-  }
+  if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }
 
 // CSR, one row per lane, stored entries in ascending column order.
-template <bool DOT>
+template <int KC>
 __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col,
                                                       const double *__restrict__ val, int64_t n,
                                                       const double *__restrict__ x,
                                                       double *__restrict__ y,
-                                                      const double *__restrict__ vdot,
+                                                      const double *__restrict__ cbase, int64_t ld,
                                                       double *__restrict__ part) {
-  __shared__ double s[kBlock / 64];
-  double a0 = 0.0;
+  constexpr int NQ = KC > 0 ? nred(KC) : 1;
+  __shared__ double red[NQ * (kBlock / 64)];
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
   for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-    double acc = 0.0;
-    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) acc = acc + val[p] * x[col[p]];
-    y[r] = acc;
-    if (DOT) a0 = fma(acc, vdot[r], a0);
+    double sum = 0.0;
+    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) sum = sum + val[p] * x[col[p]];
+    y[r] = sum;
+    if (KC > 0) accum_scalar<KC>(sum, cbase, ld, r, acc);
   }
-  if (DOT) {
-    const double t = block_sum(a0, s);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
-  }
+  if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }
 
 // ---------------------------------------------------------------------------
@@ -628,56 +795,112 @@ void launch_fill(hipStream_t st, double *x, double v, int64_t n) {
   hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, x, v, n);
 }
 
+static int stream_grid(int64_t n2, int unroll, int cap) {
+  const int64_t tile = (int64_t)kBlock * unroll;
+  int64_t g = (n2 + tile - 1) / tile;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, int *nparts) {
-  const int g = grid_for((n + 1) / 2);
+  const int g = stream_grid(n >> 1, 4, 1024);
   *nparts = g;
   hipLaunchKernelGGL(k_nrm2_part, dim3(g), dim3(kBlock), 0, st, x, n, part);
 }
 
 void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
                        int nparts, int64_t n, double *out) {
-  const int g = grid_for((n + 1) / 2);
+  const int g = stream_grid(n >> 1, 4, 1024);
   hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out);
 }
 
-void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
-                         double *y, const double *vdot, double *part, int *nparts) {
+template <int KC>
+static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
+                                  double *y, const double *cbase, int64_t ld, double *part, int *nparts) {
   const bool vec = (cols % 2 == 0) && (n % 2 == 0);
-  const int g = grid_for(vec ? n / 2 : n);
+  const int g = vec ? stream_grid(n >> 1, 2, 1024) : grid_for(n);
   if (nparts) *nparts = g;
-  if (vec) {
-    if (vdot)
-      hipLaunchKernelGGL(k_spmv_stencil_v2<true>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
-    else
-      hipLaunchKernelGGL(k_spmv_stencil_v2<false>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
-  } else {
-    if (vdot)
-      hipLaunchKernelGGL(k_spmv_stencil<true>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
-    else
-      hipLaunchKernelGGL(k_spmv_stencil<false>, dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, vdot, part);
+  if (vec)
+    hipLaunchKernelGGL((k_spmv_stencil_v2<KC>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+  else
+    hipLaunchKernelGGL((k_spmv_stencil<KC>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+}
+
+void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
+                         double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
+  switch (kc) {
+    case 0: launch_spmv_stencil_t<0>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    case 1: launch_spmv_stencil_t<1>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    case 2: launch_spmv_stencil_t<2>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    case 3: launch_spmv_stencil_t<3>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    default: launch_spmv_stencil_t<4>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
   }
 }
 
-void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
-                     int64_t n, const double *x, double *y, const double *vdot, double *part,
-                     int *nparts) {
+template <int KC>
+static void launch_spmv_csr_t(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
+                              int64_t n, const double *x, double *y, const double *cbase, int64_t ld,
+                              double *part, int *nparts) {
   const int g = grid_for(n);
   if (nparts) *nparts = g;
-  if (vdot)
-    hipLaunchKernelGGL(k_spmv_csr<true>, dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, vdot, part);
-  else
-    hipLaunchKernelGGL(k_spmv_csr<false>, dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, vdot, part);
+  hipLaunchKernelGGL((k_spmv_csr<KC>), dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, cbase, ld, part);
 }
 
-void launch_mgs_step(hipStream_t st, double *w, const double *vprev, const double *vcur,
-                     const double *part_in, int np_in, double *part_out, int *np_out,
-                     double *hout, int64_t n) {
-  const int g = grid_for((n + 1) / 2);
+void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
+                     int64_t n, const double *x, double *y, int kc, const double *cbase, int64_t ld,
+                     double *part, int *nparts) {
+  switch (kc) {
+    case 0: launch_spmv_csr_t<0>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
+    case 1: launch_spmv_csr_t<1>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
+    case 2: launch_spmv_csr_t<2>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
+    case 3: launch_spmv_csr_t<3>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
+    default: launch_spmv_csr_t<4>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
+  }
+}
+
+int mgs_grid(int64_t n, int streams) {
+  // many concurrent streams per CU thrash DRAM pages: 2 workgroups per CU for
+  // the wide passes, 4 for the narrow ones
+  const int64_t tiles = ((n >> 1) + (int64_t)kBlock * kMgsUnroll - 1) / ((int64_t)kBlock * kMgsUnroll);
+  int64_t g = streams >= 5 ? 512 : 1024;
+  if (g > tiles) g = tiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <int KP, int KC, bool NORM>
+static void launch_mgs_block_t(hipStream_t st, double *w, const double *pbase, const double *cbase,
+                               int64_t ld, const double *part_in, int np_in, double *part_out,
+                               int *np_out, double *hout, int hstride, int64_t n) {
+  const int g = mgs_grid(n, 2 + KP + KC);
   *np_out = g;
-  if (vcur)
-    hipLaunchKernelGGL(k_mgs_step<false>, dim3(g), dim3(kBlock), 0, st, w, vprev, vcur, part_in, np_in, part_out, hout, n);
-  else
-    hipLaunchKernelGGL(k_mgs_step<true>, dim3(g), dim3(kBlock), 0, st, w, vprev, vcur, part_in, np_in, part_out, hout, n);
+  hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, kMgsUnroll>), dim3(g), dim3(kBlock), 0, st, w, pbase, cbase, ld,
+                     part_in, np_in, part_out, hout, hstride, n);
+}
+
+template <int KP>
+static void launch_mgs_block_kp(hipStream_t st, int kc, double *w, const double *pbase,
+                                const double *cbase, int64_t ld, const double *part_in, int np_in,
+                                double *part_out, int *np_out, double *hout, int hstride, int64_t n) {
+  switch (kc) {
+    case 0: launch_mgs_block_t<KP, 0, true>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    case 1: launch_mgs_block_t<KP, 1, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    case 2: launch_mgs_block_t<KP, 2, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    case 3: launch_mgs_block_t<KP, 3, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    default: launch_mgs_block_t<KP, 4, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+  }
+}
+
+void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
+                      const double *cbase, int64_t ld, const double *part_in, int np_in,
+                      double *part_out, int *np_out, double *hout, int hstride, int64_t n) {
+  switch (kp) {
+    case 1: launch_mgs_block_kp<1>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    case 2: launch_mgs_block_kp<2>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    case 3: launch_mgs_block_kp<3>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+    default: launch_mgs_block_kp<4>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+  }
 }
 
 void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,

@@ -158,6 +158,9 @@ class GMRESSolver:
         check(capi.lib().kry_gmres_prev_result(self.h, x.ctypes.data_as(_dp)))
         return x
 
+    def set_mgs_block(self, k):
+        check(capi.lib().kry_gmres_set_mgs_block(self.h, k))
+
     def cycle_bytes(self, op):
         b = (C.c_double * capi.K_COUNT)()
         l = (C.c_int * capi.K_COUNT)()
@@ -180,7 +183,7 @@ class ImplicitEuler:
     """
 
     def __init__(self, ctx, corner1, corner2, cx, cy, init, params, bcs, m, tdp=False,
-                 fixed_preconditioning=False, use_graph=False, bc_time_dependent=True):
+                 fixed_preconditioning=False, use_graph=False, bc_time_dependent=True, mgs_block=None):
         L = capi.lib()
         self.ctx, self.cx, self.cy, self.m, self.tdp = ctx, cx, cy, m, tdp
         self.bc_time_dependent = bc_time_dependent
@@ -213,6 +216,8 @@ class ImplicitEuler:
         self.npad = (cx + 2) * (cy + 2)
         if use_graph:
             check(L.kry_ie_use_graph(h, 1))
+        if mgs_block is not None and m > 0:
+            check(L.kry_gmres_set_mgs_block(L.kry_ie_solver(h), mgs_block))
         self._bc_pushed = False
         self._push_bc_values(0.0)
         check(L.kry_ie_init_offdiag(h))
