@@ -72,6 +72,22 @@ void kry_ctx_destroy(kry_ctx *ctx);
 int kry_ctx_synchronize(kry_ctx *ctx);
 /* hipStream_t of the context (for event timing by the caller). */
 void *kry_ctx_stream(kry_ctx *ctx);
+/* Row-block decomposition over several processes (one per GPU).  The library
+ * owns the algorithm and calls back for the two collectives it needs; both act
+ * on DEVICE pointers and must be ordered after prior work on `stream` and
+ * before later work on it (e.g. RCCL calls enqueued on that stream).  They
+ * return 0 on success.  Has no counterpart in the reference (single process).
+ *   allreduce: in-place reduction of count doubles over all ranks
+ *   sendrecv : send count doubles to send_peer and receive count doubles from
+ *              recv_peer (a peer < 0 means: no such transfer) */
+enum kry_reduce_op { KRY_REDUCE_SUM = 0, KRY_REDUCE_MAX = 1 };
+typedef int (*kry_allreduce_fn)(void *user, double *dev_buf, int64_t count, int op, void *stream);
+typedef int (*kry_sendrecv_fn)(void *user, const double *send_dev, int send_peer, double *recv_dev,
+                               int recv_peer, int64_t count, void *stream);
+int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allreduce,
+                     kry_sendrecv_fn sendrecv, void *user);
+int kry_ctx_rank(const kry_ctx *ctx);
+int kry_ctx_nranks(const kry_ctx *ctx);
 /* Optional instrumentation (off by default): bracket every kernel launch with
  * HIP events on the context's stream and accumulate the elapsed time per
  * kernel class (enum kry_kernel_class below).  get_kernel_times synchronises
@@ -167,6 +183,18 @@ int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y,
                   const double *v0, double diffusion, double reynolds,
                   double prandtl, double eckert, const int *bc_is_dirichlet,
                   int m, int flags, kry_ie **out);
+/* The same for ONE RANK of a row-block decomposition: this rank owns the padded
+ * rows [row_begin, row_end) of the (cx+2) x (cy+2) mesh (row 0 and row cx+1 are
+ * the left / right ghost columns of the reference's layout).  T0/u0/v0 hold
+ * the interior cells of the owned rows only: cell rows
+ * i = max(row_begin,1)-1 .. min(row_end,cx+1)-2, cy values each.  The context
+ * must have collectives installed (kry_ctx_set_comm) unless the range is the
+ * whole mesh.  Every rank calls the step functions collectively. */
+int kry_ie_create_slab(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y,
+                       int cx, int cy, int row_begin, int row_end, const double *T0,
+                       const double *u0, const double *v0, double diffusion,
+                       double reynolds, double prandtl, double eckert,
+                       const int *bc_is_dirichlet, int m, int flags, kry_ie **out);
 void kry_ie_destroy(kry_ie *ie);
 /* bc(x, y, t) sampled by the host at the boundary-cell coordinates of
  * include/time_disc.hpp:55-76 for one field and side (cx values for
@@ -204,6 +232,15 @@ int kry_ie_get_bands(kry_ie *ie, double *out5);
 int kry_ie_get_rhs(kry_ie *ie, double *out);
 /* ImplicitEuler::delta (include/time_disc.hpp:380), N entries, cell numbering. */
 int kry_ie_get_delta(kry_ie *ie, double *out);
+/* Owned entries of this rank, (row_end - row_begin) * (cy+2). */
+int64_t kry_ie_local_size(const kry_ie *ie);
+/* Owned rows of a quantity in padded layout (kry_ie_local_size doubles). */
+enum kry_local_quantity {
+  KRY_LOCAL_FIELD_T = 0, KRY_LOCAL_FIELD_U = 1, KRY_LOCAL_FIELD_V = 2, KRY_LOCAL_RHS = 3,
+  KRY_LOCAL_DELTA = 4, KRY_LOCAL_BAND_W = 5, KRY_LOCAL_BAND_S = 6, KRY_LOCAL_BAND_C = 7,
+  KRY_LOCAL_BAND_N = 8, KRY_LOCAL_BAND_E = 9
+};
+int kry_ie_get_local(kry_ie *ie, int what, double *out);
 /* The solver / operator owned by the step object (borrowed handles). */
 kry_gmres *kry_ie_solver(kry_ie *ie);
 kry_op *kry_ie_operator(kry_ie *ie);

@@ -31,6 +31,9 @@ SIGNATURES = {
     "kry_ctx_destroy": (None, [_vp]),
     "kry_ctx_synchronize": (C.c_int, [_vp]),
     "kry_ctx_stream": (_vp, [_vp]),
+    "kry_ctx_set_comm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "kry_ctx_rank": (C.c_int, [_vp]),
+    "kry_ctx_nranks": (C.c_int, [_vp]),
     "kry_ctx_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "kry_ctx_get_kernel_times": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "kry_op_create_stencil": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _vpp]),
@@ -60,6 +63,9 @@ SIGNATURES = {
     "kry_ie_create": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                 _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
+    "kry_ie_create_slab": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
     "kry_ie_destroy": (None, [_vp]),
     "kry_ie_set_bc_values": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
     "kry_ie_apply_bcs": (C.c_int, [_vp]),
@@ -76,10 +82,17 @@ SIGNATURES = {
     "kry_ie_get_bands": (C.c_int, [_vp, _dp]),
     "kry_ie_get_rhs": (C.c_int, [_vp, _dp]),
     "kry_ie_get_delta": (C.c_int, [_vp, _dp]),
+    "kry_ie_local_size": (C.c_int64, [_vp]),
+    "kry_ie_get_local": (C.c_int, [_vp, C.c_int, _dp]),
     "kry_ie_solver": (_vp, [_vp]),
     "kry_ie_operator": (_vp, [_vp]),
     "kry_ie_rhs_device": (_vp, [_vp]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int64, C.c_int, _vp)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp)
+REDUCE_SUM, REDUCE_MAX = 0, 1
+LOCAL_T, LOCAL_U, LOCAL_V, LOCAL_RHS, LOCAL_DELTA = 0, 1, 2, 3, 4
 
 _lib = None
 

@@ -63,6 +63,12 @@ struct kry_ctx {
   bool timing = false;
   std::vector<hipEvent_t> free_events;
   std::vector<KernelRec> recs;
+  // row-block decomposition over several ranks (one process per GPU): the
+  // caller supplies the collectives, the library decides when to call them
+  int rank = 0, nranks = 1;
+  kry_allreduce_fn allreduce = nullptr;
+  kry_sendrecv_fn sendrecv = nullptr;
+  void *comm_user = nullptr;
 };
 
 // Brackets the launches issued in its scope with two events on the context's
@@ -106,11 +112,17 @@ struct kry_op {
   double *val = nullptr;
   int64_t nnz = 0;
   double *tx = nullptr, *ty = nullptr;  // staging for the host apply
+  bool slab = false;  // local rows of a row-block decomposition
 };
 
 struct kry_gmres {
   kry_ctx *ctx = nullptr;
   int64_t n = 0, ld = 0;
+  // slab vectors carry `halo` padding entries in front of and behind the n owned
+  // ones, the innermost halo_row of which are the neighbours' boundary rows
+  int64_t halo = 0, halo_row = 0;
+  bool offset_applied = false;  // w / vars / z already point past their front halo
+  double *tot = nullptr;  // kMaxRed totals handed to the all-reduce
   int m = 0, flags = 0;
   int kblock = kMgsBlock;  // Gram-Schmidt links fused per sweep (1 = the plain chain)
   int nvec = 0;  // subspace.size()
@@ -134,16 +146,19 @@ struct kry_gmres {
 
 struct kry_ie {
   kry_ctx *ctx = nullptr;
-  IeGeom g;
+  IeGeom g;  // cx, cy global; row0/rows: the padded rows this rank owns
   IeBc bc;
   double min_x, min_y;
-  int64_t npad = 0, neq = 0;
-  double *fld[3] = {nullptr, nullptr, nullptr};
+  int64_t nloc = 0;  // rows * (cy + 2) owned entries
+  int64_t neq = 0;   // unknowns of the whole mesh
+  int64_t halo = 0;  // padding in front of / behind every field
+  double *fld[3] = {nullptr, nullptr, nullptr};  // first owned row (halo row in front and behind)
   double *band[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double *rhs = nullptr;
-  double *bcvals = nullptr;    // device, 3 * 2 (cx+cy)
+  double *bcvals = nullptr;    // device, 3 * 2 (cx+cy), whole mesh
   double *bcvals_h = nullptr;  // pinned staging
   bool bc_dirty = true;
+  double *wrap = nullptr;  // right boundary column of T, u, v: 3 * cy
   double *parts = nullptr;
   double *maxd = nullptr;    // device scalar
   double *maxd_h = nullptr;  // pinned
@@ -151,10 +166,11 @@ struct kry_ie {
   kry_op *op = nullptr;
   kry_gmres *solver = nullptr;
   bool pending = false;  // work queued whose result has not been waited for
-  // hipGraph replay of the step
+  // hipGraph replay of the step (single rank only)
   bool use_graph = false;
   hipGraphExec_t graph_exec = nullptr;
   double graph_dt = 0.0;
+  bool whole() const { return g.row0 == 0 && g.rows == g.cx + 2; }
 };
 
 // ---------------------------------------------------------------------------
@@ -232,6 +248,22 @@ int kry_ctx_synchronize(kry_ctx *ctx) {
 
 void *kry_ctx_stream(kry_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allreduce,
+                     kry_sendrecv_fn sendrecv, void *user) {
+  if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(KRY_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+  if (nranks > 1 && (!allreduce || !sendrecv)) return fail(KRY_ERR_INVALID, "collectives are required for nranks > 1");
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  ctx->allreduce = allreduce;
+  ctx->sendrecv = sendrecv;
+  ctx->comm_user = user;
+  return KRY_OK;
+}
+
+int kry_ctx_rank(const kry_ctx *ctx) { return ctx ? ctx->rank : 0; }
+int kry_ctx_nranks(const kry_ctx *ctx) { return ctx ? ctx->nranks : 1; }
+
 int kry_ctx_set_kernel_timing(kry_ctx *ctx, int on) {
   if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
   ctx->timing = on != 0;
@@ -264,6 +296,27 @@ int kry_ctx_get_kernel_times(kry_ctx *ctx, double ms[], int launches[]) {
 static int dev_alloc(double **p, int64_t count) {
   *p = nullptr;
   HIPCHK(hipMalloc((void **)p, sizeof(double) * (size_t)(count > 0 ? count : 1)));
+  return KRY_OK;
+}
+
+// In-place reduction of `count` doubles on the device over all ranks.
+static int comm_allreduce(kry_ctx *ctx, double *buf, int64_t count, int op) {
+  if (ctx->nranks == 1) return KRY_OK;
+  const int rc = ctx->allreduce(ctx->comm_user, buf, count, op, (void *)ctx->stream);
+  if (rc != 0) return fail(KRY_ERR_STATE, "allreduce callback failed with %d", rc);
+  return KRY_OK;
+}
+
+// Fill the halo rows of a slab vector: `local` addresses the first owned row,
+// rows hold P entries, nloc entries are owned.  The lower neighbour (rank-1)
+// receives my first row as its upper halo, the upper neighbour my last row.
+static int comm_halo(kry_ctx *ctx, double *local, int64_t P, int64_t nloc) {
+  if (ctx->nranks == 1) return KRY_OK;
+  const int down = ctx->rank > 0 ? ctx->rank - 1 : -1;
+  const int up = ctx->rank + 1 < ctx->nranks ? ctx->rank + 1 : -1;
+  int rc = ctx->sendrecv(ctx->comm_user, local, down, local + nloc, up, P, (void *)ctx->stream);
+  if (rc == 0) rc = ctx->sendrecv(ctx->comm_user, local + nloc - P, up, local - P, down, P, (void *)ctx->stream);
+  if (rc != 0) return fail(KRY_ERR_STATE, "sendrecv callback failed with %d", rc);
   return KRY_OK;
 }
 
@@ -380,11 +433,11 @@ int64_t kry_op_size(const kry_op *op) { return op ? op->n : 0; }
 
 // y = A x; with kc > 0 also the partial sums of the first Gram-Schmidt group
 static void op_apply_async(kry_op *op, const double *x, double *y, int kc, const double *cbase,
-                           int64_t ld, double *part, int *nparts) {
+                           int64_t ld, double *part, int *nparts, bool x_has_halo) {
   hipStream_t st = op->ctx->stream;
   if (op->kind == 0) {
     Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
-    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts);
+    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts, x_has_halo);
   } else {
     launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, kc, cbase, ld, part, nparts);
   }
@@ -396,18 +449,20 @@ int kry_op_apply_device(kry_op *op, const double *x_dev, double *y_dev) {
   if (!op || !x_dev || !y_dev) return fail(KRY_ERR_INVALID, "NULL argument");
   if (x_dev == y_dev) return fail(KRY_ERR_INVALID, "x and y must not alias");
   HIPCHK(hipSetDevice(op->ctx->device));
-  op_apply_async(op, x_dev, y_dev, 0, nullptr, 0, nullptr, nullptr);
+  op_apply_async(op, x_dev, y_dev, 0, nullptr, 0, nullptr, nullptr, false);
   return launch_ok("kry_op_apply_device");
 }
 
 int kry_op_apply(kry_op *op, const double *x_host, double *y_host) {
   if (!op || !x_host || !y_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (op->slab && op->ctx->nranks > 1)
+    return fail(KRY_ERR_STATE, "a slab operator needs its neighbours' rows; use the solver entry points");
   HIPCHK(hipSetDevice(op->ctx->device));
   if (!op->tx) KCHK(dev_alloc(&op->tx, op->n));
   if (!op->ty) KCHK(dev_alloc(&op->ty, op->n));
   hipStream_t st = op->ctx->stream;
   HIPCHK(hipMemcpyAsync(op->tx, x_host, sizeof(double) * op->n, hipMemcpyHostToDevice, st));
-  op_apply_async(op, op->tx, op->ty, 0, nullptr, 0, nullptr, nullptr);
+  op_apply_async(op, op->tx, op->ty, 0, nullptr, 0, nullptr, nullptr, false);
   KCHK(launch_ok("kry_op_apply"));
   HIPCHK(hipMemcpyAsync(y_host, op->ty, sizeof(double) * op->n, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -419,11 +474,17 @@ int kry_op_apply(kry_op *op, const double *x_host, double *y_host) {
 // ---------------------------------------------------------------------------
 // GMRES
 // ---------------------------------------------------------------------------
-static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld; }
+static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld + g->halo; }
 
 extern "C" {
 
+static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out);
+
 int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out) {
+  return gmres_create(ctx, n, m, flags, 0, out);
+}
+
+static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out) {
   if (!ctx || !out) return fail(KRY_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (n < 1) return fail(KRY_ERR_INVALID, "system size must be positive");
@@ -433,7 +494,10 @@ int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out)
   g->ctx = ctx;
   ctx_ref(ctx);
   g->n = n;
-  g->ld = (n + 31) / 32 * 32;  // 256-byte multiple: every basis vector is 16-byte aligned
+  g->halo_row = halo_row;
+  g->halo = (halo_row + 31) / 32 * 32;
+  // 256-byte multiples: every vector starts 16-byte aligned, halo included
+  g->ld = g->halo + (n + 31) / 32 * 32 + g->halo;
   g->m = m;
   g->flags = flags;
   if (const char *e = getenv("KRY_MGS_BLOCK")) {  // experimentation knob, same range as the setter
@@ -446,6 +510,7 @@ int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out)
   if (st == KRY_OK) st = dev_alloc(&g->w, g->ld);
   if (st == KRY_OK) st = dev_alloc(&g->vars, g->ld);
   if (st == KRY_OK) st = dev_alloc(&g->parts, 2 * (int64_t)kMaxRed * kMaxParts);
+  if (st == KRY_OK) st = dev_alloc(&g->tot, kMaxRed);
   if (st == KRY_OK) st = dev_alloc(&g->beta, 1);
   if (st == KRY_OK) st = dev_alloc(&g->y, m);
   if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 2 * m);
@@ -459,10 +524,17 @@ int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out)
     return st;
   }
   hipStream_t s = ctx->stream;
-  launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
   (void)hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(m + 1) * m, s);
   (void)hipMemsetAsync(g->V, 0, sizeof(double) * (size_t)(m + 1) * g->ld, s);
   (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
+  (void)hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)g->ld, s);
+  if (g->z) (void)hipMemsetAsync(g->z, 0, sizeof(double) * (size_t)g->ld, s);
+  // work vectors are addressed at their first owned entry from here on
+  g->w += g->halo;
+  g->vars += g->halo;
+  if (g->z) g->z += g->halo;
+  g->offset_applied = true;
+  launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
   st = launch_ok("kry_gmres_create");
   if (st == KRY_OK && hipStreamSynchronize(s) != hipSuccess) st = fail(KRY_ERR_HIP, "sync failed");
   if (st != KRY_OK) {
@@ -477,7 +549,10 @@ void kry_gmres_destroy(kry_gmres *g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->stream);
-  double *bufs[] = {g->V, g->H, g->w, g->z, g->vars, g->parts, g->beta, g->y, g->work, g->bbuf, g->dd, g->ud};
+  const int64_t off = g->offset_applied ? g->halo : 0;
+  double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
+                    g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
+                    g->dd, g->ud};
   for (double *p : bufs) (void)hipFree(p);
   if (g->own_tri) {
     (void)hipFree(g->lo);
@@ -541,13 +616,27 @@ static int tdp_setup_async(kry_gmres *g, kry_op *op) {
   return launch_ok("tdp_setup");
 }
 
+// On several ranks the per-workgroup partial sums of nq quantities are
+// collapsed to nq totals and summed over the ranks; the consumer kernel then
+// reads those (np = 1).  On one rank the consumer sums the partials itself.
+static int finish_parts(kry_gmres *g, const double **part, int nq, int *np) {
+  if (g->ctx->nranks == 1) return KRY_OK;
+  launch_reduce_parts(g->ctx->stream, *part, nq, *np, g->tot);
+  KCHK(comm_allreduce(g->ctx, g->tot, nq, KRY_REDUCE_SUM));
+  *part = g->tot;
+  *np = 1;
+  return KRY_OK;
+}
+
 static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   hipStream_t st = g->ctx->stream;
   int np = 0;
   {
     ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
     launch_nrm2_part(st, b_dev, g->n, g->parts, &np);
-    launch_scale_from(st, b_dev, basis(g, 0), g->parts, np, g->n, g->beta);
+    const double *pin = g->parts;
+    KCHK(finish_parts(g, &pin, 1, &np));
+    launch_scale_from(st, b_dev, basis(g, 0), pin, np, g->n, g->beta);
   }
   g->nvec = 1;
   return launch_ok("initial_subspace");
@@ -574,29 +663,40 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   const int K = g->kblock;
   const int nv = j + 1;
   int ps = 0, kp = nv < K ? nv : K;  // previous group: start, size
+  if (g->halo_row > 0) KCHK(comm_halo(g->ctx, const_cast<double *>(src), g->halo_row, n));
   {
     // w = A v_j fused with the dots of the first group
     ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
-    op_apply_async(op, src, g->w, kp, basis(g, 0), g->ld, part[0], &np[0]);
+    op_apply_async(op, src, g->w, kp, basis(g, 0), g->ld, part[0], &np[0], g->halo_row > 0);
   }
+  const double *pin = part[0];
+  int npin = np[0];
+  KCHK(finish_parts(g, &pin, kp + kp * (kp - 1) / 2, &npin));
   int cur = 1;
   for (int cs = kp; cs < nv; cs += K, cur++) {
     const int kc = nv - cs < K ? nv - cs : K;
-    ScopedKernelTimer t(g->ctx, (kp == kMgsBlock && kc == kMgsBlock) ? KRY_K_MGS : KRY_K_MGS_PART);
-    launch_mgs_block(st, kp, kc, g->w, basis(g, ps), basis(g, cs), g->ld, part[(cur - 1) & 1],
-                     np[(cur - 1) & 1], part[cur & 1], &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
+    {
+      ScopedKernelTimer t(g->ctx, (kp == kMgsBlock && kc == kMgsBlock) ? KRY_K_MGS : KRY_K_MGS_PART);
+      launch_mgs_block(st, kp, kc, g->w, basis(g, ps), basis(g, cs), g->ld, pin, npin, part[cur & 1],
+                       &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
+    }
+    pin = part[cur & 1];
+    npin = np[cur & 1];
+    KCHK(finish_parts(g, &pin, kc + kc * (kc - 1) / 2, &npin));
     ps = cs;
     kp = kc;
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-    launch_mgs_block(st, kp, 0, g->w, basis(g, ps), nullptr, g->ld, part[(cur - 1) & 1], np[(cur - 1) & 1],
-                     part[cur & 1], &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
+    launch_mgs_block(st, kp, 0, g->w, basis(g, ps), nullptr, g->ld, pin, npin, part[cur & 1], &np[cur & 1],
+                     g->H + (int64_t)ps * g->m + j, g->m, n);
   }
+  pin = part[cur & 1];
+  npin = np[cur & 1];
+  KCHK(finish_parts(g, &pin, 1, &npin));
   {
     ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
-    launch_scale_from(st, g->w, basis(g, j + 1), part[cur & 1], np[cur & 1], n,
-                      g->H + (int64_t)(j + 1) * g->m + j);
+    launch_scale_from(st, g->w, basis(g, j + 1), pin, npin, n, g->H + (int64_t)(j + 1) * g->m + j);
   }
   g->nvec++;
   return launch_ok("add_arnoldi");
@@ -614,7 +714,7 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
-    launch_combine(st, g->V, g->ld, g->y, g->m, g->vars, g->n);
+    launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n);
   }
   if ((g->flags & KRY_GMRES_TDP) && (g->flags & KRY_GMRES_FIXED_PRECOND)) {
     launch_tdp_apply(st, g->lo, g->dd, g->ud, g->vars, g->z, g->nlines, g->L);
@@ -788,14 +888,21 @@ static int64_t padded_to_cell(const kry_ie *ie, int ip, int jp) {
 
 extern "C" {
 
-int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, int cx, int cy,
-                  const double *T0, const double *u0, const double *v0, double diffusion,
-                  double reynolds, double prandtl, double eckert, const int *bc_is_dirichlet, int m,
-                  int flags, kry_ie **out) {
-  if (!ctx || !out || !T0 || !u0 || !v0 || !bc_is_dirichlet) return fail(KRY_ERR_INVALID, "NULL argument");
+int kry_ie_create_slab(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, int cx, int cy,
+                       int row_begin, int row_end, const double *T0, const double *u0,
+                       const double *v0, double diffusion, double reynolds, double prandtl,
+                       double eckert, const int *bc_is_dirichlet, int m, int flags, kry_ie **out) {
+  if (!ctx || !out || !bc_is_dirichlet) return fail(KRY_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (cx < 1 || cy < 1) return fail(KRY_ERR_INVALID, "cells_x and cells_y must be positive");
   if ((int64_t)(cx + 2) * (cy + 2) > 2147483000LL) return fail(KRY_ERR_INVALID, "mesh too large for 32-bit cell indices");
+  if (row_begin < 0 || row_end > cx + 2 || row_end <= row_begin)
+    return fail(KRY_ERR_INVALID, "padded row range [%d, %d) is not inside [0, %d)", row_begin, row_end, cx + 2);
+  if (ctx->nranks == 1 && (row_begin != 0 || row_end != cx + 2))
+    return fail(KRY_ERR_INVALID, "a partial row range needs a context with collectives (kry_ctx_set_comm)");
+  // interior rows (cell index i) owned by this slab
+  const int ib = (row_begin > 1 ? row_begin : 1) - 1, ie_ = (row_end < cx + 1 ? row_end : cx + 1) - 1;
+  if (ie_ > ib && (!T0 || !u0 || !v0)) return fail(KRY_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(ctx->device));
   kry_ie *ie = new kry_ie;
   ie->ctx = ctx;
@@ -812,6 +919,8 @@ int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, 
   ie->min_y = min_y;
   ie->g.cx = cx;
   ie->g.cy = cy;
+  ie->g.row0 = row_begin;
+  ie->g.rows = row_end - row_begin;
   ie->g.dx = (max_x - min_x) / (double)cx;
   ie->g.dy = (max_y - min_y) / (double)cy;
   ie->g.diffusion = diffusion;
@@ -821,30 +930,37 @@ int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, 
   ie->g.inv_rp = 1.0 / (reynolds * prandtl);  // include/space_disc.hpp:61
   for (int k = 0; k < 12; k++) ie->bc.weight[k] = bc_is_dirichlet[k] ? 1.0 : 0.0;  // boundary_conds.hpp:50
   const int P = cy + 2;
-  ie->npad = (int64_t)(cx + 2) * P;
-  ie->neq = ie->npad - 4;
+  ie->nloc = (int64_t)ie->g.rows * P;
+  ie->neq = (int64_t)(cx + 2) * P - 4;
+  ie->halo = ((int64_t)P + 31) / 32 * 32;
+  const int64_t fld_len = ie->halo + (ie->nloc + 31) / 32 * 32 + ie->halo;
   int st = KRY_OK;
-  std::vector<double> host((size_t)ie->npad);
+  std::vector<double> host((size_t)fld_len);
   const double *src[3] = {T0, u0, v0};
   for (int f = 0; f < 3 && st == KRY_OK; f++) {
-    // ghosts and corners start as signalling NaN, src/mesh.cpp:34-51
+    // ghosts, corners (and the halo rows until the first exchange) start as
+    // signalling NaN, src/mesh.cpp:34-51
     for (auto &v : host) v = kSNaN;
-    for (int i = 0; i < cx; i++)
-      for (int j = 0; j < cy; j++) host[(size_t)(i + 1) * P + (j + 1)] = src[f][(size_t)i * cy + j];
-    st = dev_alloc(&ie->fld[f], ie->npad);
-    if (st == KRY_OK && hipMemcpy(ie->fld[f], host.data(), sizeof(double) * ie->npad, hipMemcpyHostToDevice) != hipSuccess)
+    for (int i = ib; i < ie_; i++)
+      for (int j = 0; j < cy; j++)
+        host[(size_t)ie->halo + (size_t)(i + 1 - row_begin) * P + (j + 1)] = src[f][(size_t)(i - ib) * cy + j];
+    double *base = nullptr;
+    st = dev_alloc(&base, fld_len);
+    if (st == KRY_OK && hipMemcpy(base, host.data(), sizeof(double) * fld_len, hipMemcpyHostToDevice) != hipSuccess)
       st = fail(KRY_ERR_HIP, "field upload failed");
+    ie->fld[f] = base ? base + ie->halo : nullptr;
   }
   for (int b = 0; b < 5 && st == KRY_OK; b++) {
-    st = dev_alloc(&ie->band[b], ie->npad);
-    if (st == KRY_OK && hipMemset(ie->band[b], 0, sizeof(double) * ie->npad) != hipSuccess) st = fail(KRY_ERR_HIP, "memset failed");
+    st = dev_alloc(&ie->band[b], ie->nloc);
+    if (st == KRY_OK && hipMemset(ie->band[b], 0, sizeof(double) * ie->nloc) != hipSuccess) st = fail(KRY_ERR_HIP, "memset failed");
   }
-  if (st == KRY_OK) st = dev_alloc(&ie->rhs, ie->npad);
-  if (st == KRY_OK && hipMemset(ie->rhs, 0, sizeof(double) * ie->npad) != hipSuccess) st = fail(KRY_ERR_HIP, "memset failed");
+  if (st == KRY_OK) st = dev_alloc(&ie->rhs, ie->nloc);
+  if (st == KRY_OK && hipMemset(ie->rhs, 0, sizeof(double) * ie->nloc) != hipSuccess) st = fail(KRY_ERR_HIP, "memset failed");
   const int nbc = 3 * 2 * (cx + cy);
   if (st == KRY_OK) st = dev_alloc(&ie->bcvals, nbc);
   if (st == KRY_OK && hipHostMalloc((void **)&ie->bcvals_h, sizeof(double) * nbc) != hipSuccess) st = fail(KRY_ERR_HIP, "pinned alloc failed");
   if (st == KRY_OK) memset(ie->bcvals_h, 0, sizeof(double) * nbc);
+  if (st == KRY_OK) st = dev_alloc(&ie->wrap, 3 * cy);
   if (st == KRY_OK) st = dev_alloc(&ie->parts, kMaxParts);
   if (st == KRY_OK) st = dev_alloc(&ie->maxd, 1);
   if (st == KRY_OK && hipHostMalloc((void **)&ie->maxd_h, sizeof(double)) != hipSuccess) st = fail(KRY_ERR_HIP, "pinned alloc failed");
@@ -853,13 +969,14 @@ int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, 
     op->ctx = ctx;
     ctx_ref(ctx);
     op->kind = 0;
-    op->rows = cx + 2;
+    op->rows = ie->g.rows;
     op->cols = P;
-    op->n = ie->npad;
+    op->n = ie->nloc;
     for (int b = 0; b < 5; b++) op->band[b] = ie->band[b];
     op->own_bands = false;
+    op->slab = !ie->whole();
     ie->op = op;
-    if (m > 0) st = kry_gmres_create(ctx, ie->npad, m, flags, &ie->solver);
+    if (m > 0) st = gmres_create(ctx, ie->nloc, m, flags, P, &ie->solver);
   }
   if (st != KRY_OK) {
     kry_ie_destroy(ie);
@@ -869,6 +986,14 @@ int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, 
   return KRY_OK;
 }
 
+int kry_ie_create(kry_ctx *ctx, double c1x, double c1y, double c2x, double c2y, int cx, int cy,
+                  const double *T0, const double *u0, const double *v0, double diffusion,
+                  double reynolds, double prandtl, double eckert, const int *bc_is_dirichlet, int m,
+                  int flags, kry_ie **out) {
+  return kry_ie_create_slab(ctx, c1x, c1y, c2x, c2y, cx, cy, 0, cx + 2, T0, u0, v0, diffusion, reynolds,
+                            prandtl, eckert, bc_is_dirichlet, m, flags, out);
+}
+
 void kry_ie_destroy(kry_ie *ie) {
   if (!ie) return;
   (void)hipSetDevice(ie->ctx->device);
@@ -876,10 +1001,12 @@ void kry_ie_destroy(kry_ie *ie) {
   if (ie->graph_exec) (void)hipGraphExecDestroy(ie->graph_exec);
   kry_gmres_destroy(ie->solver);
   kry_op_destroy(ie->op);
-  for (int f = 0; f < 3; f++) (void)hipFree(ie->fld[f]);
+  for (int f = 0; f < 3; f++)
+    if (ie->fld[f]) (void)hipFree(ie->fld[f] - ie->halo);
   for (int b = 0; b < 5; b++) (void)hipFree(ie->band[b]);
   (void)hipFree(ie->rhs);
   (void)hipFree(ie->bcvals);
+  (void)hipFree(ie->wrap);
   (void)hipFree(ie->parts);
   (void)hipFree(ie->maxd);
   if (ie->bcvals_h) (void)hipHostFree(ie->bcvals_h);
@@ -899,6 +1026,8 @@ static int ie_wait(kry_ie *ie) {
   return KRY_OK;
 }
 
+// TimeDisc::apply_bcs on a slab: hand the right boundary column to every rank,
+// fill the owned ghost cells, then refresh the halo rows of the three fields.
 static int ie_apply_bcs_async(kry_ie *ie, bool force_upload) {
   hipStream_t st = ie->ctx->stream;
   const int nbc = 3 * 2 * (ie->g.cx + ie->g.cy);
@@ -906,7 +1035,10 @@ static int ie_apply_bcs_async(kry_ie *ie, bool force_upload) {
     HIPCHK(hipMemcpyAsync(ie->bcvals, ie->bcvals_h, sizeof(double) * nbc, hipMemcpyHostToDevice, st));
     ie->bc_dirty = false;
   }
-  launch_bc_fill(st, ie->g, ie->bc, ie->fld[0], ie->fld[1], ie->fld[2], ie->bcvals);
+  launch_pack_wrap(st, ie->g, ie->fld[0], ie->fld[1], ie->fld[2], ie->wrap);
+  KCHK(comm_allreduce(ie->ctx, ie->wrap, 3 * (int64_t)ie->g.cy, KRY_REDUCE_SUM));
+  launch_bc_fill(st, ie->g, ie->bc, ie->fld[0], ie->fld[1], ie->fld[2], ie->bcvals, ie->wrap);
+  for (int f = 0; f < 3; f++) KCHK(comm_halo(ie->ctx, ie->fld[f], ie->g.cy + 2, ie->nloc));
   return KRY_OK;
 }
 
@@ -931,6 +1063,7 @@ static int ie_step_body(kry_ie *ie, double dt, bool force_upload) {
     launch_update_max(st, ie->g, ie->fld[0], ie->solver->vars, ie->parts, &np);
     launch_max_final(st, ie->parts, np, ie->maxd);
   }
+  KCHK(comm_allreduce(ie->ctx, ie->maxd, 1, KRY_REDUCE_MAX));
   KCHK(launch_ok("timestep"));
   HIPCHK(hipMemcpyAsync(ie->maxd_h, ie->maxd, sizeof(double), hipMemcpyDeviceToHost, st));
   return KRY_OK;
@@ -939,7 +1072,7 @@ static int ie_step_body(kry_ie *ie, double dt, bool force_upload) {
 static int ie_step_async(kry_ie *ie, double dt) {
   if (!ie->solver) return fail(KRY_ERR_STATE, "step object was created without a solver");
   hipStream_t st = ie->ctx->stream;
-  if (!ie->use_graph) {
+  if (!ie->use_graph || ie->ctx->nranks > 1) {
     KCHK(ie_step_body(ie, dt, false));
   } else {
     if (!ie->graph_exec || ie->graph_dt != dt) {
@@ -948,7 +1081,6 @@ static int ie_step_async(kry_ie *ie, double dt) {
         HIPCHK(hipGraphExecDestroy(ie->graph_exec));
         ie->graph_exec = nullptr;
       }
-      // the preconditioner work buffers must exist before capture (no allocation inside it)
       hipGraph_t graph = nullptr;
       const bool was_timing = ie->ctx->timing;
       ie->ctx->timing = false;  // no event records inside a capture
@@ -1050,35 +1182,50 @@ int kry_ie_use_graph(kry_ie *ie, int on) {
 
 double kry_ie_time(const kry_ie *ie) { return ie ? ie->time : 0.0; }
 int64_t kry_ie_num_eqns(const kry_ie *ie) { return ie ? ie->neq : 0; }
+int64_t kry_ie_local_size(const kry_ie *ie) { return ie ? ie->nloc : 0; }
 kry_gmres *kry_ie_solver(kry_ie *ie) { return ie ? ie->solver : nullptr; }
 kry_op *kry_ie_operator(kry_ie *ie) { return ie ? ie->op : nullptr; }
 const double *kry_ie_rhs_device(kry_ie *ie) { return ie ? ie->rhs : nullptr; }
 
-int kry_ie_get_field(kry_ie *ie, int field, double *out_padded) {
-  if (!ie || !out_padded) return fail(KRY_ERR_INVALID, "NULL argument");
-  if (field < 0 || field > 2) return fail(KRY_ERR_INVALID, "bad field");
-  HIPCHK(hipSetDevice(ie->ctx->device));
-  HIPCHK(hipMemcpyAsync(out_padded, ie->fld[field], sizeof(double) * ie->npad, hipMemcpyDeviceToHost, ie->ctx->stream));
+static int download(kry_ie *ie, const double *dev, double *out, int64_t count) {
+  HIPCHK(hipMemcpyAsync(out, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ie->ctx->stream));
   HIPCHK(hipStreamSynchronize(ie->ctx->stream));
   ie->pending = false;
   return KRY_OK;
+}
+
+int kry_ie_get_local(kry_ie *ie, int what, double *out) {
+  if (!ie || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  const double *src = nullptr;
+  if (what >= KRY_LOCAL_FIELD_T && what <= KRY_LOCAL_FIELD_V) src = ie->fld[what];
+  else if (what == KRY_LOCAL_RHS) src = ie->rhs;
+  else if (what == KRY_LOCAL_DELTA) src = ie->solver ? ie->solver->vars : nullptr;
+  else if (what >= KRY_LOCAL_BAND_W && what <= KRY_LOCAL_BAND_E) src = ie->band[what - KRY_LOCAL_BAND_W];
+  if (!src) return fail(KRY_ERR_INVALID, "unknown quantity %d", what);
+  return download(ie, src, out, ie->nloc);
+}
+
+int kry_ie_get_field(kry_ie *ie, int field, double *out_padded) {
+  if (!ie || !out_padded) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (field < 0 || field > 2) return fail(KRY_ERR_INVALID, "bad field");
+  if (!ie->whole()) return fail(KRY_ERR_STATE, "this rank owns a slab only; use kry_ie_get_local");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  return download(ie, ie->fld[field], out_padded, ie->nloc);
 }
 
 int kry_ie_get_bands(kry_ie *ie, double *out5) {
   if (!ie || !out5) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!ie->whole()) return fail(KRY_ERR_STATE, "this rank owns a slab only; use kry_ie_get_local");
   HIPCHK(hipSetDevice(ie->ctx->device));
-  for (int b = 0; b < 5; b++)
-    HIPCHK(hipMemcpyAsync(out5 + (size_t)b * ie->npad, ie->band[b], sizeof(double) * ie->npad, hipMemcpyDeviceToHost, ie->ctx->stream));
-  HIPCHK(hipStreamSynchronize(ie->ctx->stream));
-  ie->pending = false;
+  for (int b = 0; b < 5; b++) KCHK(download(ie, ie->band[b], out5 + (size_t)b * ie->nloc, ie->nloc));
   return KRY_OK;
 }
 
 static int compact_download(kry_ie *ie, const double *dev, double *out) {
-  std::vector<double> host((size_t)ie->npad);
-  HIPCHK(hipMemcpyAsync(host.data(), dev, sizeof(double) * ie->npad, hipMemcpyDeviceToHost, ie->ctx->stream));
-  HIPCHK(hipStreamSynchronize(ie->ctx->stream));
-  ie->pending = false;
+  if (!ie->whole()) return fail(KRY_ERR_STATE, "this rank owns a slab only; use kry_ie_get_local");
+  std::vector<double> host((size_t)ie->nloc);
+  KCHK(download(ie, dev, host.data(), ie->nloc));
   const int P = ie->g.cy + 2;
   for (int ip = 0; ip < ie->g.cx + 2; ip++)
     for (int jp = 0; jp < P; jp++) {
@@ -1103,8 +1250,9 @@ int kry_ie_get_delta(kry_ie *ie, double *out) {
 
 int kry_ie_get_dense_system(kry_ie *ie, double *out) {
   if (!ie || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!ie->whole()) return fail(KRY_ERR_STATE, "this rank owns a slab only");
   HIPCHK(hipSetDevice(ie->ctx->device));
-  std::vector<double> bands((size_t)5 * ie->npad);
+  std::vector<double> bands((size_t)5 * ie->nloc);
   KCHK(kry_ie_get_bands(ie, bands.data()));
   const int64_t N = ie->neq;
   const int P = ie->g.cy + 2, R = ie->g.cx + 2;
@@ -1119,7 +1267,7 @@ int kry_ie_get_dense_system(kry_ie *ie, double *out) {
         if (ni < 0 || ni >= R || nj < 0 || nj >= P) continue;
         const int64_t c = padded_to_cell(ie, ni, nj);
         if (c < 0) continue;
-        const double v = bands[(size_t)b * ie->npad + (size_t)ip * P + jp];
+        const double v = bands[(size_t)b * ie->nloc + (size_t)ip * P + jp];
         if (v != 0.0) out[r * N + c] = v;
       }
     }

@@ -32,10 +32,12 @@ void launch_scale_from(hipStream_t st, const double *src, double *dst, const dou
                        int nparts, int64_t n, double *out);
 
 // y = A x; with kc > 0 also the partial sums of <y, c_k> and <c_a, c_b> for the
-// kc vectors cbase + k*ld (layout: part[q * kMaxParts + workgroup], dots first)
+// kc vectors cbase + k*ld (layout: part[q * nparts + workgroup], dots first)
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                          double *y, int kc, const double *cbase, int64_t ld, double *part,
-                         int *nparts);
+                         int *nparts, bool x_has_halo);
+// tot[q] = sum_i part[q * np + i], q < nq (one workgroup)
+void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot);
 void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
                      int64_t n, const double *x, double *y, int kc, const double *cbase, int64_t ld,
                      double *part, int *nparts);
@@ -69,7 +71,8 @@ void launch_fill(hipStream_t st, double *x, double v, int64_t n);
 
 // ---- implicit-Euler assembly ------------------------------------------------
 struct IeGeom {
-  int cx, cy;
+  int cx, cy;      // interior cells of the whole mesh
+  int row0, rows;  // padded rows [row0, row0 + rows) owned by this rank
   double dx, dy;
   double diffusion, reynolds, prandtl, eckert, inv_rp;
 };
@@ -77,8 +80,10 @@ struct IeBc {
   double weight[12];  // [field*4 + side]
 };
 
+void launch_pack_wrap(hipStream_t st, const IeGeom &g, const double *T, const double *u,
+                      const double *v, double *wrap);
 void launch_bc_fill(hipStream_t st, const IeGeom &g, const IeBc &bc, double *T, double *u,
-                    double *v, const double *bcvals);
+                    double *v, const double *bcvals, const double *wrap);
 void launch_offdiag(hipStream_t st, const IeGeom &g, const double *u, const double *v, double *bw,
                     double *bs, double *bc, double *bn, double *be);
 void launch_assemble(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,

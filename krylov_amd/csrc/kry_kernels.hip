@@ -72,14 +72,14 @@ __device__ __forceinline__ void sum_parts_multi(const double *__restrict__ part,
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int q = wv; q < NQ; q += kBlock / 64) {
     double a = 0.0;
-    for (int i = lane; i < np; i += 64) a += part[(size_t)q * kMaxParts + i];
+    for (int i = lane; i < np; i += 64) a += part[(size_t)q * np + i];
     a = wave_sum(a);
     if (lane == 0) tot[q] = a;
   }
   __syncthreads();
 }
 
-// Block-level reduction of NQ accumulators into part[q * kMaxParts + blockIdx.x].
+// Block-level reduction of NQ accumulators into part[q * gridDim.x + blockIdx.x].
 template <int NQ>
 __device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? NQ : 1], double *red /* LDS NQ*4 */,
                                                     double *__restrict__ part) {
@@ -94,7 +94,7 @@ __device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? 
     double t = red[threadIdx.x * (kBlock / 64)];
 #pragma unroll
     for (int i = 1; i < kBlock / 64; i++) t += red[threadIdx.x * (kBlock / 64) + i];
-    part[(size_t)threadIdx.x * kMaxParts + blockIdx.x] = t;
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
   }
 }
 
@@ -105,6 +105,19 @@ __device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? 
 __global__ __launch_bounds__(kBlock) void k_fill(double *__restrict__ x, double v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
     x[i] = v;
+}
+
+// tot[q] = sum_i part[q * np + i]: collapses the per-workgroup partial sums to
+// one value per quantity so that ranks can all-reduce a handful of doubles.
+__global__ __launch_bounds__(kBlock) void k_reduce_parts(const double *__restrict__ part, int nq, int np,
+                                                          double *__restrict__ tot) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int q = wv; q < nq; q += kBlock / 64) {
+    double a = 0.0;
+    for (int i = lane; i < np; i += 64) a += part[(size_t)q * np + i];
+    a = wave_sum(a);
+    if (lane == 0) tot[q] = a;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_nrm2_part(const double *__restrict__ x, int64_t n,
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict_
 // (multiply, then subtract) while taking the dots of the following group.
 // KC = 0 with NORM: the last pass of an Arnoldi step, accumulates <w, w>.
 //
-// Partial sums: part[q * kMaxParts + workgroup], q < KC + KC (KC-1)/2 (dots
+// Partial sums: part[q * gridDim.x + workgroup], q < KC + KC (KC-1)/2 (dots
 // first, then Gram entries in (a, b) lexicographic order), or q = 0 for NORM.
 // ---------------------------------------------------------------------------
 template <int KP, int KC, bool NORM, int U>
@@ -343,7 +356,7 @@ __device__ __forceinline__ void accum_scalar(double r, const double *__restrict_
 
 // Row sum in ascending column order starting from +0.0:
 //   ((((0 + w x[k-P]) + s x[k-1]) + c x[k]) + n x[k+1]) + e x[k+P]
-template <int KC>
+template <int KC, bool HALO>
 __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int P,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ y,
@@ -355,11 +368,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
-    const double xw = (k >= P) ? x[k - P] : 0.0;
-    const double xs = (k >= 1) ? x[k - 1] : 0.0;
+    const double xw = (HALO || k >= P) ? x[k - P] : 0.0;
+    const double xs = (HALO || k >= 1) ? x[k - 1] : 0.0;
     const double xc = x[k];
-    const double xn = (k + 1 < n) ? x[k + 1] : 0.0;
-    const double xe = (k + P < n) ? x[k + P] : 0.0;
+    const double xn = (HALO || k + 1 < n) ? x[k + 1] : 0.0;
+    const double xe = (HALO || k + P < n) ? x[k + P] : 0.0;
     double r = 0.0;
     r = r + b.w[k] * xw;
     r = r + b.s[k] * xs;
@@ -372,11 +385,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
   if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }
 
+// HALO: x is the local slab of a row-block decomposition with one valid row of
+// P entries in front of x[0] and behind x[n-1] (the neighbours' boundary rows,
+// or zeros at the ends of the mesh), so no bounds checks are needed.
+//
 // Vectorised form for even P and even n: every lane owns two consecutive
 // unknowns; band, centre and +-P accesses are aligned 16-byte loads.  Bands,
 // partners and the result are streamed non-temporally; x keeps the default
 // policy because its rows are reused by the neighbouring rows' sums.
-template <int KC>
+template <int KC, bool HALO>
 __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, int P,
                                                              const double *__restrict__ x,
                                                              double *__restrict__ y,
@@ -406,10 +423,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
       if (i < n2) {
         const int64_t k = 2 * i;
         const d2 xc = x2[i];
-        const d2 xw = (i >= P2) ? x2[i - P2] : zero;
-        const d2 xe = (i + P2 < n2) ? x2[i + P2] : zero;
-        const double xm1 = (k >= 1) ? x[k - 1] : 0.0;
-        const double xp2 = (k + 2 < n) ? x[k + 2] : 0.0;
+        const d2 xw = (HALO || i >= P2) ? x2[i - P2] : zero;
+        const d2 xe = (HALO || i + P2 < n2) ? x2[i + P2] : zero;
+        const double xm1 = (HALO || k >= 1) ? x[k - 1] : 0.0;
+        const double xp2 = (HALO || k + 2 < n) ? x[k + 2] : 0.0;
         const d2 cw = ld_nt(&bw[i]), cs = ld_nt(&bs[i]), cc = ld_nt(&bc[i]), cn = ld_nt(&bn[i]), ce = ld_nt(&be[i]);
         d2 cv[KC > 0 ? KC : 1];
 #pragma unroll
@@ -611,14 +628,37 @@ __device__ __forceinline__ double ghost_cell(double bndry, double bc, double siz
   return (2.0 * bc - bndry) * weight + (size * bc + bndry) * (1.0 - weight);
 }
 
+// Slab geometry: a rank owns the padded rows [row0, row0 + rows) of the
+// (cx+2) x (cy+2) mesh; field and vector pointers address its first owned row
+// and have one valid halo row of P entries in front and behind.  A single GPU
+// owns everything (row0 = 0, rows = cx + 2).
+
+// Copy of the right boundary column (interior cells of padded row cx) of the
+// three fields, wrap[f * cy + j]; zeros on ranks that do not own that row, so
+// that a sum over ranks hands the column to everybody.
+__global__ __launch_bounds__(kBlock) void k_pack_wrap(IeGeom g, const double *__restrict__ T,
+                                                       const double *__restrict__ u,
+                                                       const double *__restrict__ v,
+                                                       double *__restrict__ wrap) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 3 * g.cy) return;
+  const int f = t / g.cy, j = t % g.cy;
+  const int P = g.cy + 2;
+  const int lr = g.cx - g.row0;  // local index of padded row cx
+  const double *F = f == 0 ? T : (f == 1 ? u : v);
+  wrap[t] = (lr >= 0 && lr < g.rows) ? F[(size_t)lr * P + (j + 1)] : 0.0;
+}
+
 // All twelve ghost fills of TimeDisc::apply_bcs (include/time_disc.hpp:146-163)
 // in one launch: each reads interior cells only and writes its own ghost
 // strip, so their order is immaterial.  View wiring as in the TimeDisc
-// constructor (:51-134): left conditions read the RIGHT boundary column.
-// bcvals layout per field: [bottom cx][top cx][left cy][right cy].
+// constructor (:51-134): left conditions read the RIGHT boundary column, which
+// (like the right conditions' source) is taken from `wrap`.
+// bcvals layout per field: [bottom cx][top cx][left cy][right cy], global.
 __global__ __launch_bounds__(kBlock) void k_bc_fill(IeGeom g, IeBc bc, double *__restrict__ T,
                                                      double *__restrict__ u, double *__restrict__ v,
-                                                     const double *__restrict__ bcvals) {
+                                                     const double *__restrict__ bcvals,
+                                                     const double *__restrict__ wrap) {
   const int per_field = 2 * (g.cx + g.cy);
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= 3 * per_field) return;
@@ -627,30 +667,25 @@ __global__ __launch_bounds__(kBlock) void k_bc_fill(IeGeom g, IeBc bc, double *_
   double *F = f == 0 ? T : (f == 1 ? u : v);
   const int P = g.cy + 2;
   const double bcv = bcvals[(size_t)f * per_field + r];
-#define FAT(i, j) F[(size_t)((i) + 1) * P + ((j) + 1)]
-  if (r < g.cx) {  // bottom
-    const int i = r;
-    FAT(i, -1) = ghost_cell(FAT(i, 0), bcv, g.dy, bc.weight[f * 4 + KRY_SIDE_BOTTOM]);
+  if (r < 2 * g.cx) {  // bottom (r < cx) or top ghost of interior column i
+    const bool top = r >= g.cx;
+    const int i = top ? r - g.cx : r;
+    const int lr = i + 1 - g.row0;
+    if (lr < 0 || lr >= g.rows) return;
+    double *row = F + (size_t)lr * P;
+    if (top)
+      row[g.cy + 1] = ghost_cell(row[g.cy], bcv, g.dy, bc.weight[f * 4 + KRY_SIDE_TOP]);
+    else
+      row[0] = ghost_cell(row[1], bcv, g.dy, bc.weight[f * 4 + KRY_SIDE_BOTTOM]);
     return;
   }
-  r -= g.cx;
-  if (r < g.cx) {  // top
-    const int i = r;
-    FAT(i, g.cy) = ghost_cell(FAT(i, g.cy - 1), bcv, g.dy, bc.weight[f * 4 + KRY_SIDE_TOP]);
-    return;
-  }
-  r -= g.cx;
-  if (r < g.cy) {  // left ghost column, fed from the right boundary column
-    const int j = r;
-    FAT(-1, j) = ghost_cell(FAT(g.cx - 1, j), bcv, g.dx, bc.weight[f * 4 + KRY_SIDE_LEFT]);
-    return;
-  }
-  r -= g.cy;
-  {
-    const int j = r;
-    FAT(g.cx, j) = ghost_cell(FAT(g.cx - 1, j), bcv, g.dx, bc.weight[f * 4 + KRY_SIDE_RIGHT]);
-  }
-#undef FAT
+  r -= 2 * g.cx;
+  const bool right = r >= g.cy;
+  const int j = right ? r - g.cy : r;
+  const int lr = (right ? g.cx + 1 : 0) - g.row0;
+  if (lr < 0 || lr >= g.rows) return;
+  F[(size_t)lr * P + (j + 1)] = ghost_cell(wrap[f * g.cy + j], bcv, g.dx,
+                                           bc.weight[f * 4 + (right ? KRY_SIDE_RIGHT : KRY_SIDE_LEFT)]);
 }
 
 // Off-diagonal bands, include/time_disc.hpp:249-274 with
@@ -663,9 +698,9 @@ __global__ __launch_bounds__(kBlock) void k_offdiag(IeGeom g, const double *__re
                                                      double *__restrict__ bc, double *__restrict__ bn,
                                                      double *__restrict__ be) {
   const int P = g.cy + 2;
-  const int64_t npad = (int64_t)(g.cx + 2) * P;
-  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < npad; k += (int64_t)gridDim.x * kBlock) {
-    const int ip = (int)(k / P), jp = (int)(k % P);
+  const int64_t nloc = (int64_t)g.rows * P;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = g.row0 + (int)(k / P), jp = (int)(k % P);
     const bool interior = ip >= 1 && ip <= g.cx && jp >= 1 && jp <= g.cy;
     const bool corner = (ip == 0 || ip == g.cx + 1) && (jp == 0 || jp == g.cy + 1);
     double w = 0.0, s = 0.0, n = 0.0, e = 0.0;
@@ -699,10 +734,10 @@ __global__ __launch_bounds__(kBlock) void k_assemble(IeGeom g, IeBc bc, double d
                                                       double *__restrict__ be,
                                                       double *__restrict__ rhs) {
   const int P = g.cy + 2;
-  const int64_t npad = (int64_t)(g.cx + 2) * P;
+  const int64_t nloc = (int64_t)g.rows * P;
   const double dx = g.dx, dy = g.dy;
-  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < npad; k += (int64_t)gridDim.x * kBlock) {
-    const int ip = (int)(k / P), jp = (int)(k % P);
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = g.row0 + (int)(k / P), jp = (int)(k % P);
     const bool xin = ip >= 1 && ip <= g.cx, yin = jp >= 1 && jp <= g.cy;
     if (xin && yin) {
       const double Dx0 = 2.0 * g.diffusion * g.inv_rp / (dx * dx);
@@ -756,10 +791,10 @@ __global__ __launch_bounds__(kBlock) void k_update_max(IeGeom g, double *__restr
                                                         double *__restrict__ part) {
   __shared__ double s[kBlock / 64];
   const int P = g.cy + 2;
-  const int64_t npad = (int64_t)(g.cx + 2) * P;
+  const int64_t nloc = (int64_t)g.rows * P;
   double m = 0.0;
-  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < npad; k += (int64_t)gridDim.x * kBlock) {
-    const int ip = (int)(k / P), jp = (int)(k % P);
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = g.row0 + (int)(k / P), jp = (int)(k % P);
     if (ip >= 1 && ip <= g.cx && jp >= 1 && jp <= g.cy) {
       const double d = delta[k];
       T[k] = T[k] + d;
@@ -815,27 +850,41 @@ void launch_scale_from(hipStream_t st, const double *src, double *dst, const dou
   hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out);
 }
 
-template <int KC>
+template <int KC, bool HALO>
 static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                                   double *y, const double *cbase, int64_t ld, double *part, int *nparts) {
   const bool vec = (cols % 2 == 0) && (n % 2 == 0);
   const int g = vec ? stream_grid(n >> 1, 2, 1024) : grid_for(n);
   if (nparts) *nparts = g;
   if (vec)
-    hipLaunchKernelGGL((k_spmv_stencil_v2<KC>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
   else
-    hipLaunchKernelGGL((k_spmv_stencil<KC>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+    hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+}
+
+template <bool HALO>
+static void launch_spmv_stencil_h(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
+                                  double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
+  switch (kc) {
+    case 0: launch_spmv_stencil_t<0, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    case 1: launch_spmv_stencil_t<1, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    case 2: launch_spmv_stencil_t<2, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    case 3: launch_spmv_stencil_t<3, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+    default: launch_spmv_stencil_t<4, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
+  }
 }
 
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
-                         double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
-  switch (kc) {
-    case 0: launch_spmv_stencil_t<0>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    case 1: launch_spmv_stencil_t<1>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    case 2: launch_spmv_stencil_t<2>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    case 3: launch_spmv_stencil_t<3>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    default: launch_spmv_stencil_t<4>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-  }
+                         double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts,
+                         bool x_has_halo) {
+  if (x_has_halo)
+    launch_spmv_stencil_h<true>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+  else
+    launch_spmv_stencil_h<false>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+}
+
+void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot) {
+  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, part, nq, np, tot);
 }
 
 template <int KC>
@@ -931,29 +980,35 @@ void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t
   hipLaunchKernelGGL(k_tdp_extract_csr, dim3(grid_for(n)), dim3(kBlock), 0, st, rowptr, col, val, n, lo, di, up);
 }
 
+void launch_pack_wrap(hipStream_t st, const IeGeom &g, const double *T, const double *u,
+                      const double *v, double *wrap) {
+  const int total = 3 * g.cy;
+  hipLaunchKernelGGL(k_pack_wrap, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g, T, u, v, wrap);
+}
+
 void launch_bc_fill(hipStream_t st, const IeGeom &g, const IeBc &bc, double *T, double *u,
-                    double *v, const double *bcvals) {
+                    double *v, const double *bcvals, const double *wrap) {
   const int total = 3 * 2 * (g.cx + g.cy);
-  hipLaunchKernelGGL(k_bc_fill, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g, bc, T, u, v, bcvals);
+  hipLaunchKernelGGL(k_bc_fill, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g, bc, T, u, v, bcvals, wrap);
 }
 
 void launch_offdiag(hipStream_t st, const IeGeom &g, const double *u, const double *v, double *bw,
                     double *bs, double *bc, double *bn, double *be) {
-  const int64_t npad = (int64_t)(g.cx + 2) * (g.cy + 2);
-  hipLaunchKernelGGL(k_offdiag, dim3(grid_for(npad)), dim3(kBlock), 0, st, g, u, v, bw, bs, bc, bn, be);
+  const int64_t nloc = (int64_t)g.rows * (g.cy + 2);
+  hipLaunchKernelGGL(k_offdiag, dim3(grid_for(nloc)), dim3(kBlock), 0, st, g, u, v, bw, bs, bc, bn, be);
 }
 
 void launch_assemble(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,
                      const double *u, const double *v, double *bw, double *bs, double *bcn,
                      double *bn, double *be, double *rhs) {
-  const int64_t npad = (int64_t)(g.cx + 2) * (g.cy + 2);
-  hipLaunchKernelGGL(k_assemble, dim3(grid_for(npad)), dim3(kBlock), 0, st, g, bc, dt, T, u, v, bw, bs, bcn, bn, be, rhs);
+  const int64_t nloc = (int64_t)g.rows * (g.cy + 2);
+  hipLaunchKernelGGL(k_assemble, dim3(grid_for(nloc)), dim3(kBlock), 0, st, g, bc, dt, T, u, v, bw, bs, bcn, bn, be, rhs);
 }
 
 void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double *delta,
                        double *part, int *nparts) {
-  const int64_t npad = (int64_t)(g.cx + 2) * (g.cy + 2);
-  const int gr = grid_for(npad);
+  const int64_t nloc = (int64_t)g.rows * (g.cy + 2);
+  const int gr = grid_for(nloc);
   *nparts = gr;
   hipLaunchKernelGGL(k_update_max, dim3(gr), dim3(kBlock), 0, st, g, T, delta, part);
 }
