@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mesh", type=int, default=8192, help="cells per side of the square mesh")
-    ap.add_argument("--m", type=int, default=50, help="GMRES subspace size (num_iters)")
+    ap.add_argument("--gmres-m", dest="m", type=int, default=50, help="GMRES subspace size (num_iters)")
     ap.add_argument("--dt", type=float, default=0.25)
     ap.add_argument("--graph", action="store_true", help="replay the step through a hipGraph")
     ap.add_argument("--no-kernel-timing", action="store_true")

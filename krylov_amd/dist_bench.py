@@ -1,0 +1,97 @@
+"""bench.py for N > 1: the same mesh as the single-GPU run, split into row
+blocks, one rank per GPU (strong scaling), halo rows and dot products over
+RCCL (torch.distributed backend "nccl")."""
+import json
+import os
+import time
+
+
+def run(args, world, rank, local_rank):
+    import torch
+    import torch.distributed as dist
+    from krylov_amd import capi, host, problems
+    from krylov_amd.dist import TorchComm, partition_rows
+
+    backend = os.environ.get("KRY_DIST_BACKEND", "nccl")
+    device = local_rank
+    if backend != "nccl":
+        # rehearsal on fewer GPUs than ranks: host-staged collectives let ranks share a device
+        device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
+    dist.init_process_group(backend)
+    ctx = host.Context(device)
+    comm = TorchComm(ctx)
+    n_side, m, dt = args.mesh, args.m, args.dt
+    ranges = partition_rows(n_side + 2, world)
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(n_side), m=m, bc_time_dependent=False,
+                             row_range=ranges[rank])
+    N = dev.n
+    nloc = dev.nloc
+    for _ in range(args.warmup):
+        dev.timestep(dt)
+    timing = not args.no_kernel_timing
+    ctx.set_kernel_timing(timing)
+    ctx.kernel_times()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    last = 0.0
+    for _ in range(args.steps):
+        last = dev.timestep(dt)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms, cnt = ctx.kernel_times()
+    ctx.set_kernel_timing(False)
+    # slowest rank defines the job time
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        bytes_cycle, launches_cycle = dev.solver().cycle_bytes(dev.operator())
+        kernels = {}
+        for k, name in enumerate(capi.K_NAMES):
+            if cnt[k] == 0:
+                continue
+            per_launch = bytes_cycle[k] / launches_cycle[k] if launches_cycle[k] else None
+            avg_ms = ms[k] / cnt[k]
+            kernels[name] = {"launches": cnt[k], "total_ms": round(ms[k], 3), "avg_ms": round(avg_ms, 4),
+                             "alg_bytes_per_launch": per_launch,
+                             "gbps": round(per_launch / (avg_ms * 1e-3) / 1e9, 1) if per_launch else None}
+        roofline = None
+        if "mgs_block_full" in kernels:
+            k = kernels["mgs_block_full"]
+            per_launch = 80.0 * nloc
+            achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,2> on rank 0's row block",
+                        "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],
+                        "launches_timed": k["launches"]}
+        kernel_ms = sum(ms)
+        out = {
+            "metric": "gmres_arnoldi_iters_per_sec",
+            "value": m * args.steps / elapsed,
+            "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "S-iso %dx%d mesh, implicit-Euler step with fixed-m GMRES(%d), "
+                                   "modified Gram-Schmidt, 5-band stencil operator" % (n_side, n_side, m),
+                       "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
+                       "parallelism": "row blocks over %d GPUs (halo rows + all-reduced dots, %s)" % (world, backend),
+                       "rows_per_rank": [b - a for a, b in ranges]},
+            "last_max_delta": last,
+            "rank0_kernel_ms_per_step": round(kernel_ms / args.steps, 2),
+            "rank0_comm_and_gap_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms / args.steps, 2),
+            "collectives_per_step": {k: v // (args.steps + args.warmup + 1) for k, v in comm.calls.items()},
+            "kernels": kernels,
+            "roofline": roofline,
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -183,9 +183,13 @@ class ImplicitEuler:
     """
 
     def __init__(self, ctx, corner1, corner2, cx, cy, init, params, bcs, m, tdp=False,
-                 fixed_preconditioning=False, use_graph=False, bc_time_dependent=True, mgs_block=None):
+                 fixed_preconditioning=False, use_graph=False, bc_time_dependent=True, mgs_block=None,
+                 row_range=None):
+        """row_range=(begin, end): own only these padded rows of the mesh (one
+        rank of a row-block decomposition; the context needs collectives)."""
         L = capi.lib()
         self.ctx, self.cx, self.cy, self.m, self.tdp = ctx, cx, cy, m, tdp
+        self.row_range = (0, cx + 2) if row_range is None else (int(row_range[0]), int(row_range[1]))
         self.bc_time_dependent = bc_time_dependent
         self.bcs = {}
         flags = (C.c_int * 12)()
@@ -201,19 +205,23 @@ class ImplicitEuler:
         max_y = max(corner1[1], corner2[1])
         self.dx = (max_x - self.min_x) / float(cx)
         self.dy = (max_y - self.min_y) / float(cy)
-        xs = self.median_x(np.arange(cx))
+        r0, r1 = self.row_range
+        ib, ie = max(r0, 1) - 1, min(r1, cx + 1) - 1  # interior cell rows owned
+        self.interior_rows = (ib, max(ie, ib))
+        xs = self.median_x(np.arange(ib, max(ie, ib)))
         ys = self.median_y(np.arange(cy))
         T0, u0, v0 = init(xs[:, None], ys[None, :])
-        T0, u0, v0 = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (cx, cy)))
+        T0, u0, v0 = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (len(xs), cy)))
                       for a in (T0, u0, v0))
         gflags = (GMRES_TDP if tdp else 0) | (GMRES_FIXED_PRECOND if fixed_preconditioning else 0)
         h = C.c_void_p()
-        check(L.kry_ie_create(ctx.h, corner1[0], corner1[1], corner2[0], corner2[1], cx, cy,
-                              T0.ctypes.data_as(_dp), u0.ctypes.data_as(_dp), v0.ctypes.data_as(_dp),
-                              params[0], params[1], params[2], params[3], flags, m, gflags, C.byref(h)))
+        check(L.kry_ie_create_slab(ctx.h, corner1[0], corner1[1], corner2[0], corner2[1], cx, cy, r0, r1,
+                                   T0.ctypes.data_as(_dp), u0.ctypes.data_as(_dp), v0.ctypes.data_as(_dp),
+                                   params[0], params[1], params[2], params[3], flags, m, gflags, C.byref(h)))
         self.h = h
         self.n = L.kry_ie_num_eqns(h)
         self.npad = (cx + 2) * (cy + 2)
+        self.nloc = L.kry_ie_local_size(h)
         if use_graph:
             check(L.kry_ie_use_graph(h, 1))
         if mgs_block is not None and m > 0:
@@ -294,6 +302,12 @@ class ImplicitEuler:
         check(capi.lib().kry_ie_get_field(self.h, f, a.ctypes.data_as(_dp)))
         return a
 
+    def local(self, what):
+        """Owned rows of a quantity (capi.LOCAL_*), shape (rows, cy + 2)."""
+        a = np.empty((self.row_range[1] - self.row_range[0], self.cy + 2))
+        check(capi.lib().kry_ie_get_local(self.h, what, a.ctypes.data_as(_dp)))
+        return a
+
     def bands(self):
         a = np.empty((5, self.cx + 2, self.cy + 2))
         check(capi.lib().kry_ie_get_bands(self.h, a.ctypes.data_as(_dp)))
@@ -315,7 +329,7 @@ class ImplicitEuler:
         return a
 
     def solver(self):
-        return GMRESSolver(self.ctx, self.npad, self.m, self.tdp,
+        return GMRESSolver(self.ctx, self.nloc, self.m, self.tdp,
                            handle=C.c_void_p(capi.lib().kry_ie_solver(self.h)))
 
     def operator(self):
