@@ -1,0 +1,180 @@
+// TimeDisc / ImplicitEuler with the interface of the reference's
+// include/time_disc.hpp; all state lives on the device (kry_ie_*), the host
+// object keeps the configuration, the boundary functions and a mirror Mesh
+// that is refreshed on demand.
+#ifndef KRYLOV_HOST_TIME_DISC_HPP_
+#define KRYLOV_HOST_TIME_DISC_HPP_
+
+#include <functional>
+#include <utility>
+#include <vector>
+
+#include "boundary_conds.hpp"
+#include "mesh.hpp"
+#include "solver.hpp"
+#include "space_disc.hpp"
+
+using BCSpec = std::pair<BCType, std::function<real(real, real, real)>>;
+
+inline BCSpec default_bc() {
+  return {BCType::Dirichlet, [](real, real, real) { return 0.0; }};
+}
+
+constexpr unsigned long num_eqns(int num_x_cells, int num_y_cells, int num_ghost_cells) {
+  return (num_x_cells + 2 * num_ghost_cells) * (num_y_cells + 2 * num_ghost_cells) - 4;
+}
+
+template <typename SpaceDisc_> class TimeDisc {
+public:
+  using SpaceDisc = SpaceDisc_;
+
+  // BC order as in the reference: temperature bottom, top, left, right, then
+  // the same for vel_u and vel_v (include/time_disc.hpp:23-50).
+  TimeDisc(const std::pair<real, real> corner_1, const std::pair<real, real> corner_2, const size_t x_cells,
+           const size_t y_cells, std::function<triple(real, real)> initial_t_u_v, const SpaceDisc &space_,
+           BCSpec bottom_temp = default_bc(), BCSpec top_temp = default_bc(), BCSpec left_temp = default_bc(),
+           BCSpec right_temp = default_bc(), BCSpec bottom_u = default_bc(), BCSpec top_u = default_bc(),
+           BCSpec left_u = default_bc(), BCSpec right_u = default_bc(), BCSpec bottom_v = default_bc(),
+           BCSpec top_v = default_bc(), BCSpec left_v = default_bc(), BCSpec right_v = default_bc())
+      : cur_state(corner_1, corner_2, x_cells, y_cells, initial_t_u_v), space(space_), corner_1_(corner_1),
+        corner_2_(corner_2),
+        bcs_{bottom_temp, top_temp, left_temp, right_temp, bottom_u, top_u, left_u, right_u, bottom_v, top_v, left_v,
+             right_v} {}
+
+  virtual ~TimeDisc() {
+    if (ie_) kry_ie_destroy(ie_);
+  }
+  TimeDisc(const TimeDisc &) = delete;
+  TimeDisc &operator=(const TimeDisc &) = delete;
+
+  // Host copy of the current state (fields are fetched from the device).
+  const Mesh &mesh() {
+    if (ie_)
+      for (int f = 0; f < 3; f++) krylov::check(kry_ie_get_field(ie_, f, cur_state.data(f)), "kry_ie_get_field");
+    return cur_state;
+  }
+  const SpaceDisc &space_disc() noexcept { return space; }
+  real cur_time() const noexcept { return ie_ ? kry_ie_time(ie_) : 0.0; }
+  real diffusion() const noexcept { return space.diffusion(); }
+  real reynolds() const noexcept { return space.reynolds(); }
+  real prandtl() const noexcept { return space.prandtl(); }
+  real eckert() const noexcept { return space.eckert(); }
+
+protected:
+  // Creates the device object for a solver with m iterations.
+  void create_device(int m, int flags) {
+    const int cx = cur_state.cells_x(), cy = cur_state.cells_y();
+    std::vector<real> T((size_t)cx * cy), u((size_t)cx * cy), v((size_t)cx * cy);
+    for (int i = 0; i < cx; i++)
+      for (int j = 0; j < cy; j++) {
+        T[(size_t)i * cy + j] = cur_state.Temp(i, j);
+        u[(size_t)i * cy + j] = cur_state.vel_u(i, j);
+        v[(size_t)i * cy + j] = cur_state.vel_v(i, j);
+      }
+    int dirichlet[12];
+    for (int k = 0; k < 12; k++) dirichlet[k] = bcs_[k].first == BCType::Dirichlet;
+    krylov::check(kry_ie_create(krylov::default_context(), corner_1_.first, corner_1_.second, corner_2_.first,
+                                corner_2_.second, cx, cy, T.data(), u.data(), v.data(), space.diffusion(),
+                                space.reynolds(), space.prandtl(), space.eckert(), dirichlet, m, flags, &ie_),
+                  "kry_ie_create");
+  }
+
+  // Samples the twelve boundary functions at the reference's coordinates
+  // (include/time_disc.hpp:55-76) for the current time.
+  void push_bc_values() {
+    const int cx = cur_state.cells_x(), cy = cur_state.cells_y();
+    const real t = cur_time();
+    std::vector<real> vals;
+    for (int f = 0; f < 3; f++)
+      for (int side = 0; side < 4; side++) {
+        const auto &fn = bcs_[f * 4 + side].second;
+        const bool horiz = side == KRY_SIDE_BOTTOM || side == KRY_SIDE_TOP;
+        vals.resize(horiz ? cx : cy);
+        for (int k = 0; k < (int)vals.size(); k++) {
+          real x, y;
+          if (side == KRY_SIDE_BOTTOM) { x = cur_state.median_x(k); y = cur_state.bottom_y(0); }
+          else if (side == KRY_SIDE_TOP) { x = cur_state.median_x(k); y = cur_state.top_y(cy - 1); }
+          else if (side == KRY_SIDE_LEFT) { x = cur_state.left_x(0); y = cur_state.median_y(k); }
+          else { x = cur_state.right_x(cx - 1); y = cur_state.median_y(k); }
+          vals[k] = fn(x, y, t);
+        }
+        krylov::check(kry_ie_set_bc_values(ie_, f, side, vals.data(), (int)vals.size()), "kry_ie_set_bc_values");
+      }
+  }
+
+  void apply_bcs() {
+    push_bc_values();
+    krylov::check(kry_ie_apply_bcs(ie_), "kry_ie_apply_bcs");
+  }
+
+  Mesh cur_state;
+  SpaceDisc space;
+  std::pair<real, real> corner_1_, corner_2_;
+  BCSpec bcs_[12];
+  kry_ie *ie_ = nullptr;
+};
+
+template <typename SpaceDisc_, typename Solver_> class ImplicitEuler : public TimeDisc<SpaceDisc_> {
+public:
+  using Solver = Solver_;
+  using SpaceDisc = SpaceDisc_;
+  using Base = TimeDisc<SpaceDisc_>;
+
+  template <typename... BCs>
+  ImplicitEuler(const std::pair<real, real> corner_1, const std::pair<real, real> corner_2, const size_t cells_x,
+                const size_t cells_y, std::function<triple(real, real)> initial_t_u_v, const SpaceDisc &space,
+                BCs... bcs)
+      : Base(corner_1, corner_2, cells_x, cells_y, initial_t_u_v, space, bcs...),
+        n_(num_eqns((int)cells_x, (int)cells_y, Mesh::ghost_cells)) {
+    this->create_device((int)Solver::iterations, Solver::device_flags);
+    // second half of the reference constructor (include/time_disc.hpp:246-274)
+    this->push_bc_values();
+    krylov::check(kry_ie_init_offdiag(this->ie_), "kry_ie_init_offdiag");
+  }
+
+  real timestep(const real dt) {
+    this->push_bc_values();
+    real max_delta = 0.0;
+    krylov::check(kry_ie_timestep(this->ie_, dt, &max_delta), "kry_ie_timestep");
+    return max_delta;
+  }
+
+  std::pair<const matrix &, const vector &> assemble_system(const real dt) {
+    this->push_bc_values();
+    krylov::check(kry_ie_assemble_system(this->ie_, dt), "kry_ie_assemble_system");
+    return {sys(), sol()};
+  }
+
+  // include/time_disc.hpp:341-376
+  unsigned long cell_idx(const int i, const int j) const noexcept {
+    const int cy = this->cur_state.cells_y(), gc = Mesh::ghost_cells;
+    if (i == -gc) return j;
+    if (i == this->cur_state.cells_x()) return cy + i * (cy + 2 * gc) + j;
+    return cy + i * (cy + 2 * gc) + gc + j;
+  }
+
+  // Dense copies in the reference's numbering (small meshes only).
+  const matrix &sys() {
+    system_ = matrix(matrix::shape_type{n_, n_});
+    krylov::check(kry_ie_get_dense_system(this->ie_, system_.data()), "kry_ie_get_dense_system");
+    return system_;
+  }
+  const vector &sol() {
+    sol_vec_ = vector(vector::shape_type{n_});
+    krylov::check(kry_ie_get_rhs(this->ie_, sol_vec_.data()), "kry_ie_get_rhs");
+    return sol_vec_;
+  }
+  const vector &delta() {
+    delta_ = vector(vector::shape_type{n_});
+    krylov::check(kry_ie_get_delta(this->ie_, delta_.data()), "kry_ie_get_delta");
+    return delta_;
+  }
+  void use_graph(bool on) { krylov::check(kry_ie_use_graph(this->ie_, on ? 1 : 0), "kry_ie_use_graph"); }
+
+protected:
+  unsigned long n_;
+  matrix system_;
+  vector sol_vec_, delta_;
+};
+
+#endif  // KRYLOV_HOST_TIME_DISC_HPP_
