@@ -132,7 +132,7 @@ def main():
                     traffic = tj.get("mgs_block_full_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,2> (Gram-Schmidt sweep: 4 projections applied + 4 dots)",
+        roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,1> (Gram-Schmidt sweep: 4 projections applied + 4 dots)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],

@@ -12,6 +12,8 @@
 //    (stencil row sums, w -= h v, x += y v, assembly) is rounded exactly like
 //    the reference's scalar C++; fma() is used explicitly only inside
 //    reductions, whose summation order differs from the reference anyway.
+#include <stdlib.h>
+
 #include "kry_internal.h"
 
 namespace kry {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
 // unknowns; band, centre and +-P accesses are aligned 16-byte loads.  Bands,
 // partners and the result are streamed non-temporally; x keeps the default
 // policy because its rows are reused by the neighbouring rows' sums.
-template <int KC, bool HALO>
+template <int KC, bool HALO, int U>
 __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, int P,
                                                              const double *__restrict__ x,
                                                              double *__restrict__ y,
@@ -414,7 +416,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
-  constexpr int U = 2;
   const int64_t tile = (int64_t)kBlock * U;
   for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
 #pragma unroll
@@ -830,6 +831,23 @@ void launch_fill(hipStream_t st, double *x, double v, int64_t n) {
   hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, x, v, n);
 }
 
+// Launch shape of a streaming sweep over `streams` arrays.  Measured on
+// MI355X: HBM efficiency is best when the number of concurrently advancing
+// stream heads (streams x workgroups) stays near the number of DRAM banks
+// (~4096) and the grid is a multiple of the 256 CUs; wide sweeps want one
+// 16-byte element per lane and stream in flight, narrow ones four.
+constexpr int sweep_unroll(int streams) { return streams >= 8 ? 1 : (streams >= 5 ? 2 : 4); }
+
+int sweep_grid(int64_t n2, int streams, int unroll) {
+  int64_t g = 4096 / streams / 256 * 256;
+  if (g < 256) g = 256;
+  if (g > 1024) g = 1024;
+  const int64_t tiles = (n2 + (int64_t)kBlock * unroll - 1) / ((int64_t)kBlock * unroll);
+  if (g > tiles) g = tiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 static int stream_grid(int64_t n2, int unroll, int cap) {
   const int64_t tile = (int64_t)kBlock * unroll;
   int64_t g = (n2 + tile - 1) / tile;
@@ -854,10 +872,16 @@ template <int KC, bool HALO>
 static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                                   double *y, const double *cbase, int64_t ld, double *part, int *nparts) {
   const bool vec = (cols % 2 == 0) && (n % 2 == 0);
-  const int g = vec ? stream_grid(n >> 1, 2, 1024) : grid_for(n);
+  // 13+ streams with cached x rows: two elements per lane, one workgroup per CU (measured optimum)
+  constexpr int U = 2;
+  int g = grid_for(n);
+  if (vec) {
+    const int64_t tiles = ((n >> 1) + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
+    g = (int)(tiles < 256 ? tiles : 256);
+  }
   if (nparts) *nparts = g;
   if (vec)
-    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
   else
     hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
 }
@@ -908,23 +932,15 @@ void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, 
   }
 }
 
-int mgs_grid(int64_t n, int streams) {
-  // many concurrent streams per CU thrash DRAM pages: 2 workgroups per CU for
-  // the wide passes, 4 for the narrow ones
-  const int64_t tiles = ((n >> 1) + (int64_t)kBlock * kMgsUnroll - 1) / ((int64_t)kBlock * kMgsUnroll);
-  int64_t g = streams >= 5 ? 512 : 1024;
-  if (g > tiles) g = tiles;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-
 template <int KP, int KC, bool NORM>
 static void launch_mgs_block_t(hipStream_t st, double *w, const double *pbase, const double *cbase,
                                int64_t ld, const double *part_in, int np_in, double *part_out,
                                int *np_out, double *hout, int hstride, int64_t n) {
-  const int g = mgs_grid(n, 2 + KP + KC);
+  constexpr int streams = 2 + KP + KC;
+  constexpr int U = sweep_unroll(streams);
+  const int g = sweep_grid(n >> 1, streams, U);
   *np_out = g;
-  hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, kMgsUnroll>), dim3(g), dim3(kBlock), 0, st, w, pbase, cbase, ld,
+  hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, U>), dim3(g), dim3(kBlock), 0, st, w, pbase, cbase, ld,
                      part_in, np_in, part_out, hout, hstride, n);
 }
 

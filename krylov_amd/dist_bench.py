@@ -66,7 +66,7 @@ def run(args, world, rank, local_rank):
             k = kernels["mgs_block_full"]
             per_launch = 80.0 * nloc
             achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,2> on rank 0's row block",
+            roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,1> on rank 0's row block",
                         "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": None,
                         "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],

@@ -179,6 +179,50 @@ __global__ __launch_bounds__(BLK) void v3(double *w, const double *p1, const dou
   if (threadIdx.x == 0) { const int G = gridDim.x; part[blockIdx.x] = t0; part[G + blockIdx.x] = t1; part[2 * G + blockIdx.x] = t2; part[3 * G + blockIdx.x] = t3; part[4 * G + blockIdx.x] = t4; part[5 * G + blockIdx.x] = t5; }
 }
 
+
+// V4: four links per pass (9 reads, 1 write, 4 dots + 6 Gram entries), as k_mgs_block<4,4>
+template <int BLK, int U>
+__global__ __launch_bounds__(BLK) void v4(double *w, const double *pbase, const double *cbase, long ld, double *part, long n2) {
+  __shared__ double s[BLK / 64];
+  d2 *w2 = (d2 *)w;
+  double acc[10];
+  for (int q = 0; q < 10; q++) acc[q] = 0.0;
+  const double h[4] = {1e-3, 2e-3, 3e-3, 4e-3};
+  const long tile = (long)BLK * U;
+  for (long base = (long)blockIdx.x * tile; base < n2; base += (long)gridDim.x * tile) {
+    d2 wv[U], pv[4][U], cv[4][U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long i = base + u * BLK + threadIdx.x;
+      if (i < n2) {
+        wv[u] = __builtin_nontemporal_load(&w2[i]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) pv[k][u] = __builtin_nontemporal_load((const d2 *)(pbase + k * ld) + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cv[k][u] = __builtin_nontemporal_load((const d2 *)(cbase + k * ld) + i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long i = base + u * BLK + threadIdx.x;
+      if (i < n2) {
+        d2 r = wv[u];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r = r - h[k] * pv[k][u];
+        __builtin_nontemporal_store(r, &w2[i]);
+        int q = 4;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          acc[a] = fma(r.x, cv[a][u].x, acc[a]); acc[a] = fma(r.y, cv[a][u].y, acc[a]);
+#pragma unroll
+          for (int b = a + 1; b < 4; b++) { acc[q] = fma(cv[a][u].x, cv[b][u].x, acc[q]); acc[q] = fma(cv[a][u].y, cv[b][u].y, acc[q]); q++; }
+        }
+      }
+    }
+  }
+  for (int q = 0; q < 10; q++) { double t = block_sum<BLK>(acc[q], s); if (threadIdx.x == 0) part[q * gridDim.x + blockIdx.x] = t; }
+}
+
 // plain copy for calibration
 template <int BLK, int U, bool NT>
 __global__ __launch_bounds__(BLK) void vcopy(double *w, const double *p, long n2) {
@@ -234,23 +278,18 @@ int main(int argc, char **argv) {
 #define P(r) v[1 + ((r) % 3)]
 #define Cc(r) v[4 + ((r) % 3)]
   char nm[128];
-  run("read3 BLK256 U4 G2048", 24, [&](int r) { hipLaunchKernelGGL((vread3<256, 4>), dim3(2048), dim3(256), 0, 0, v[0], P(r), Cc(r), part, n2); });
-  run("V1 BLK256 U4 G1024 NT (ref)", 32, [&](int r) { hipLaunchKernelGGL((v1<256, 4, true>), dim3(1024), dim3(256), 0, 0, v[0], P(r), Cc(r), 1e-3, part, n2); });
-  for (int G : {512, 768, 1024, 1280, 1536, 2048}) {
-    snprintf(nm, sizeof nm, "V1P NT-all U4 G%d np=G", G); run(nm, 32, [&](int r) { hipLaunchKernelGGL((v1p<256, 4, 0>), dim3(G), dim3(256), 0, 0, v[0], P(r), Cc(r), part + 100000, G, part, n2); });
-    snprintf(nm, sizeof nm, "V1P NT-all U8 G%d np=G", G); run(nm, 32, [&](int r) { hipLaunchKernelGGL((v1p<256, 8, 0>), dim3(G), dim3(256), 0, 0, v[0], P(r), Cc(r), part + 100000, G, part, n2); });
+  // nine vectors with leading dimension ld for the 4+4 sweep
+  double *big; const long ld = (n + 31) / 32 * 32;
+  CHECK(hipMalloc((void **)&big, sizeof(double) * ld * 9)); CHECK(hipMemset(big, 0, sizeof(double) * ld * 9));
+  run("V1 single link NT U4 G1024 (ref)", 32, [&](int r) { hipLaunchKernelGGL((v1<256, 4, true>), dim3(1024), dim3(256), 0, 0, v[0], P(r), Cc(r), 1e-3, part, n2); });
+  for (int G : {256, 384, 512, 640, 768, 1024, 1536, 2048}) {
+    snprintf(nm, sizeof nm, "V4 4+4 sweep U1 G%d", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((v4<256, 1>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 5 * ld, ld, part, n2); });
+    snprintf(nm, sizeof nm, "V4 4+4 sweep U2 G%d", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((v4<256, 2>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 5 * ld, ld, part, n2); });
+    snprintf(nm, sizeof nm, "V4 4+4 sweep U3 G%d", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((v4<256, 3>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 5 * ld, ld, part, n2); });
   }
-  run("V1P NT p,c only U4 G1024", 32, [&](int r) { hipLaunchKernelGGL((v1p<256, 4, 1>), dim3(1024), dim3(256), 0, 0, v[0], P(r), Cc(r), part + 100000, 1024, part, n2); });
-  run("V1P NT loads, plain store U4 G1024", 32, [&](int r) { hipLaunchKernelGGL((v1p<256, 4, 2>), dim3(1024), dim3(256), 0, 0, v[0], P(r), Cc(r), part + 100000, 1024, part, n2); });
-  run("V1P NT-all BLK512 U4 G512", 32, [&](int r) { hipLaunchKernelGGL((v1p<512, 4, 0>), dim3(512), dim3(512), 0, 0, v[0], P(r), Cc(r), part + 100000, 512, part, n2); });
-  run("V1P NT-all BLK512 U2 G1024", 32, [&](int r) { hipLaunchKernelGGL((v1p<512, 2, 0>), dim3(1024), dim3(512), 0, 0, v[0], P(r), Cc(r), part + 100000, 1024, part, n2); });
-  for (int G : {512, 1024, 2048}) {
-    snprintf(nm, sizeof nm, "V2 pair NT U2 G%d", G); run(nm, 48, [&](int r) { hipLaunchKernelGGL((v2<256, 2, true>), dim3(G), dim3(256), 0, 0, v[0], v[1], v[2], v[3 + r % 2], v[5 + r % 2], 1e-3, 2e-3, part, n2); });
-    snprintf(nm, sizeof nm, "V2 pair NT U3 G%d", G); run(nm, 48, [&](int r) { hipLaunchKernelGGL((v2<256, 3, true>), dim3(G), dim3(256), 0, 0, v[0], v[1], v[2], v[3 + r % 2], v[5 + r % 2], 1e-3, 2e-3, part, n2); });
-    snprintf(nm, sizeof nm, "V2 pair NT U4 G%d", G); run(nm, 48, [&](int r) { hipLaunchKernelGGL((v2<256, 4, true>), dim3(G), dim3(256), 0, 0, v[0], v[1], v[2], v[3 + r % 2], v[5 + r % 2], 1e-3, 2e-3, part, n2); });
-    snprintf(nm, sizeof nm, "V3 triple NT U1 G%d", G); run(nm, 64, [&](int r) { hipLaunchKernelGGL((v3<256, 1>), dim3(G), dim3(256), 0, 0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], 1e-3, 2e-3, 3e-3, part, n2); });
-    snprintf(nm, sizeof nm, "V3 triple NT U2 G%d", G); run(nm, 64, [&](int r) { hipLaunchKernelGGL((v3<256, 2>), dim3(G), dim3(256), 0, 0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], 1e-3, 2e-3, 3e-3, part, n2); });
-    snprintf(nm, sizeof nm, "V3 triple NT U3 G%d", G); run(nm, 64, [&](int r) { hipLaunchKernelGGL((v3<256, 3>), dim3(G), dim3(256), 0, 0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], 1e-3, 2e-3, 3e-3, part, n2); });
+  for (int G : {128, 256, 512}) {
+    snprintf(nm, sizeof nm, "V4 4+4 sweep BLK512 U1 G%d", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((v4<512, 1>), dim3(G), dim3(512), 0, 0, big, big + ld, big + 5 * ld, ld, part, n2); });
+    snprintf(nm, sizeof nm, "V4 4+4 sweep BLK512 U2 G%d", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((v4<512, 2>), dim3(G), dim3(512), 0, 0, big, big + ld, big + 5 * ld, ld, part, n2); });
   }
   return 0;
 }
