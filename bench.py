@@ -40,6 +40,11 @@ def parse_args():
     ap.add_argument("--gmres-m", dest="m", type=int, default=50, help="GMRES subspace size (num_iters)")
     ap.add_argument("--dt", type=float, default=0.25)
     ap.add_argument("--graph", action="store_true", help="replay the step through a hipGraph")
+    ap.add_argument("--problem", choices=["s_iso", "s_aniso"], default="s_iso",
+                    help="s_iso: square cells, diagonally dominant; s_aniso: 40 x 1 channel, high CFL along y")
+    ap.add_argument("--tdp", action="store_true", help="tridiagonal (line) right preconditioner")
+    ap.add_argument("--fixed-precond", action="store_true",
+                    help="apply the preconditioner to the result as well (the reference does not)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-m", type=int, default=8, help="Arnoldi steps of the CPU sample cycle")
@@ -84,8 +89,8 @@ def main():
     ctx = host.Context(local_rank)
     n_side, m, dt = args.mesh, args.m, args.dt
     t_setup = time.perf_counter()
-    dev = host.ImplicitEuler(ctx, **problems.s_iso(n_side), m=m, bc_time_dependent=False,
-                             use_graph=args.graph)
+    dev = host.ImplicitEuler(ctx, **getattr(problems, args.problem)(n_side), m=m, bc_time_dependent=False,
+                             use_graph=args.graph, tdp=args.tdp, fixed_preconditioning=args.fixed_precond)
     ctx.synchronize()
     t_setup = time.perf_counter() - t_setup
     N = dev.n
@@ -146,8 +151,11 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "S-iso %dx%d mesh, implicit-Euler step with fixed-m GMRES(%d), "
-                               "modified Gram-Schmidt, 5-band stencil operator" % (n_side, n_side, m),
+        "config": {"workload": "%s %dx%d mesh, implicit-Euler step with fixed-m GMRES(%d)%s, "
+                               "modified Gram-Schmidt, 5-band stencil operator"
+                               % ({"s_iso": "S-iso", "s_aniso": "S-aniso"}[args.problem], n_side, n_side, m,
+                                  (" + line preconditioner" + (" (applied to the result)" if args.fixed_precond else ""))
+                                  if args.tdp else ""),
                    "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
                    "parallelism": "1 GPU", "graph": bool(args.graph)},
         "hbm_gbps_whole_step": round(total_alg / elapsed / 1e9, 1),

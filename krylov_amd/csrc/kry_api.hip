@@ -717,8 +717,8 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
     launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n);
   }
   if ((g->flags & KRY_GMRES_TDP) && (g->flags & KRY_GMRES_FIXED_PRECOND)) {
-    launch_tdp_apply(st, g->lo, g->dd, g->ud, g->vars, g->z, g->nlines, g->L);
-    HIPCHK(hipMemcpyAsync(g->vars, g->z, sizeof(double) * g->n, hipMemcpyDeviceToDevice, st));
+    ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
+    launch_tdp_apply(st, g->lo, g->dd, g->ud, g->vars, g->vars, g->nlines, g->L);
   }
   KCHK(launch_ok("solve"));
   if (x_dev) HIPCHK(hipMemcpyAsync(x_dev, g->vars, sizeof(double) * g->n, hipMemcpyDeviceToDevice, st));
@@ -866,8 +866,11 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
   bytes[KRY_K_COMBINE] = (m + 1) * N;
   launches[KRY_K_COMBINE] = 1;
   if (g->flags & KRY_GMRES_TDP) {
-    bytes[KRY_K_PRECOND] = 5.0 * N + m * 6.0 * N;  // factor: 3 read 2 write; apply: lo,dd,ud,sol read, out written twice
-    launches[KRY_K_PRECOND] = m + 1;
+    // factor: lo,di,up read, dd,ud written; apply: forward sweep reads sol,lo,dd and writes out,
+    // backward sweep reads out,ud and writes out
+    const int applies = m + ((g->flags & KRY_GMRES_FIXED_PRECOND) ? 1 : 0);
+    bytes[KRY_K_PRECOND] = 5.0 * N + applies * 7.0 * N;
+    launches[KRY_K_PRECOND] = applies + 1;
   }
   return KRY_OK;
 }

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "kry_internal.h"
+#include <cstdlib>
 
 namespace kry {
 
@@ -558,46 +559,245 @@ __global__ __launch_bounds__(kBlock) void k_small_solve(const double *__restrict
 // in the reference's numbering), each solved by the Thomas recurrences of the
 // reference in the same order.  The pivots do not depend on the right-hand
 // side, so they are computed once per assembled matrix.
+//
+// Device form: one wavefront owns LPW lines.  A chunk of kTdpC = 64 columns of
+// those lines is fetched with lane = column (each load instruction moves one
+// line's 512 contiguous bytes), parked in LDS, and then lane l < LPW walks
+// line l through the chunk out of LDS (row pitch 65 doubles: conflict-free in
+// both directions).  The next chunk's loads are issued before the walk and land
+// in registers while the dependent chain (one multiply-subtract and one true
+// division per element) runs, results go back through LDS so that the stores
+// are coalesced again.  The chain is latency-bound, so idle lanes cost
+// nothing and LPW is chosen for enough wavefronts to cover the memory
+// latency, not to fill lanes.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_tdp_factor(const double *__restrict__ lo,
-                                                        const double *__restrict__ di,
-                                                        const double *__restrict__ up,
-                                                        double *__restrict__ dd,
-                                                        double *__restrict__ ud, int64_t nlines,
-                                                        int64_t L) {
-  const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (line >= nlines) return;
-  const int64_t b = line * L;
-  double diag = di[b];
-  double uprev = up[b] / diag;
-  dd[b] = diag;
-  ud[b] = uprev;
-  for (int64_t j = 1; j < L; j++) {
-    diag = di[b + j] - uprev * lo[b + j];
-    uprev = up[b + j] / diag;
-    dd[b + j] = diag;
-    ud[b + j] = uprev;
+constexpr int kTdpC = 64;
+
+template <int LPW>
+struct TdpTile {
+  double v[LPW][kTdpC + 1];
+};
+
+template <int LPW>
+__device__ __forceinline__ void tdp_fetch(double (&r)[LPW], const double *__restrict__ a, int64_t line0,
+                                          int nl, int64_t L, int64_t col, double fill) {
+#pragma unroll
+  for (int i = 0; i < LPW; i++) r[i] = (i < nl && col < L) ? a[(line0 + i) * L + col] : fill;
+}
+
+template <int LPW>
+__device__ __forceinline__ void tdp_park(TdpTile<LPW> &t, const double (&r)[LPW], int lane) {
+#pragma unroll
+  for (int i = 0; i < LPW; i++) t.v[i][lane] = r[i];
+}
+
+template <int LPW>
+__device__ __forceinline__ void tdp_flush(const TdpTile<LPW> &t, double *a, int64_t line0, int nl,
+                                          int64_t L, int64_t col, int lane) {
+#pragma unroll
+  for (int i = 0; i < LPW; i++)
+    if (i < nl && col < L) a[(line0 + i) * L + col] = t.v[i][lane];
+}
+
+// The walks below run in one lane per line.  A full chunk is processed in
+// register blocks of kTdpB elements whose LDS reads are issued one block ahead
+// of the dependent chain; a partial chunk takes the plain loop.
+constexpr int kTdpB = 8;
+
+template <int LPW>
+__device__ __forceinline__ void tdp_ld_block(double (&r)[kTdpB], const TdpTile<LPW> &t, int lane, int j0) {
+#pragma unroll
+  for (int k = 0; k < kTdpB; k++) r[k] = t.v[lane][j0 + k];
+}
+
+template <int LPW>
+__device__ __forceinline__ void tdp_st_block(TdpTile<LPW> &t, const double (&r)[kTdpB], int lane, int j0) {
+#pragma unroll
+  for (int k = 0; k < kTdpB; k++) t.v[lane][j0 + k] = r[k];
+}
+
+// forward elimination over one chunk: y_j = (s_j - y_{j-1} lo_j) / dd_j
+template <int LPW>
+__device__ __forceinline__ double tdp_walk_forward(TdpTile<LPW> &ts, const TdpTile<LPW> &ta,
+                                                   const TdpTile<LPW> &td, int lane, int cw, double prev) {
+  if (cw == kTdpC) {
+    double sv[2][kTdpB], av[2][kTdpB], dv[2][kTdpB];
+    tdp_ld_block<LPW>(sv[0], ts, lane, 0);
+    tdp_ld_block<LPW>(av[0], ta, lane, 0);
+    tdp_ld_block<LPW>(dv[0], td, lane, 0);
+#pragma unroll
+    for (int b = 0; b < kTdpC / kTdpB; b++) {
+      const int cur = b & 1;
+      if (b + 1 < kTdpC / kTdpB) {
+        tdp_ld_block<LPW>(sv[cur ^ 1], ts, lane, (b + 1) * kTdpB);
+        tdp_ld_block<LPW>(av[cur ^ 1], ta, lane, (b + 1) * kTdpB);
+        tdp_ld_block<LPW>(dv[cur ^ 1], td, lane, (b + 1) * kTdpB);
+      }
+#pragma unroll
+      for (int k = 0; k < kTdpB; k++) {
+        prev = (sv[cur][k] - prev * av[cur][k]) / dv[cur][k];
+        sv[cur][k] = prev;
+      }
+      tdp_st_block<LPW>(ts, sv[cur], lane, b * kTdpB);
+    }
+  } else {
+    for (int j = 0; j < cw; j++) {
+      prev = (ts.v[lane][j] - prev * ta.v[lane][j]) / td.v[lane][j];
+      ts.v[lane][j] = prev;
+    }
+  }
+  return prev;
+}
+
+// back substitution over elements jtop..0 of one chunk: x_j = y_j - x_{j+1} ud_j
+template <int LPW>
+__device__ __forceinline__ double tdp_walk_backward(TdpTile<LPW> &ts, const TdpTile<LPW> &ta, int lane,
+                                                    int jtop, double prev) {
+  if (jtop == kTdpC - 1) {
+    double sv[2][kTdpB], av[2][kTdpB];
+    constexpr int NB = kTdpC / kTdpB;
+    tdp_ld_block<LPW>(sv[0], ts, lane, (NB - 1) * kTdpB);
+    tdp_ld_block<LPW>(av[0], ta, lane, (NB - 1) * kTdpB);
+#pragma unroll
+    for (int b = NB - 1; b >= 0; b--) {
+      const int cur = (NB - 1 - b) & 1;
+      if (b > 0) {
+        tdp_ld_block<LPW>(sv[cur ^ 1], ts, lane, (b - 1) * kTdpB);
+        tdp_ld_block<LPW>(av[cur ^ 1], ta, lane, (b - 1) * kTdpB);
+      }
+#pragma unroll
+      for (int k = kTdpB - 1; k >= 0; k--) {
+        prev = sv[cur][k] - prev * av[cur][k];
+        sv[cur][k] = prev;
+      }
+      tdp_st_block<LPW>(ts, sv[cur], lane, b * kTdpB);
+    }
+  } else {
+    for (int j = jtop; j >= 0; j--) {
+      prev = ts.v[lane][j] - prev * ta.v[lane][j];
+      ts.v[lane][j] = prev;
+    }
+  }
+  return prev;
+}
+
+// Pivots dd and normalised upper diagonal ud of every line
+// (include/solver.hpp:252-261 without the right-hand-side part).  The first
+// element of a line has no predecessor: its lower coefficient is taken as +0
+// and the running value starts at +0, which leaves d_0 = di_0 exactly.
+template <int LPW>
+__global__ __launch_bounds__(kTdpC) void k_tdp_factor(const double *__restrict__ lo,
+                                                       const double *__restrict__ di,
+                                                       const double *__restrict__ up,
+                                                       double *__restrict__ dd,
+                                                       double *__restrict__ ud, int64_t nlines,
+                                                       int64_t L) {
+  __shared__ TdpTile<LPW> ta, td, tu;
+  const int lane = threadIdx.x;
+  const int64_t line0 = (int64_t)blockIdx.x * LPW;
+  const int nl = (int)((nlines - line0) < LPW ? (nlines - line0) : LPW);
+  const int64_t nchunk = (L + kTdpC - 1) / kTdpC;
+  double ra[LPW], rd[LPW], ru[LPW];
+  tdp_fetch<LPW>(ra, lo, line0, nl, L, lane, 0.0);
+  tdp_fetch<LPW>(rd, di, line0, nl, L, lane, 1.0);
+  tdp_fetch<LPW>(ru, up, line0, nl, L, lane, 0.0);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < LPW; i++) ra[i] = 0.0;
+  }
+  double uprev = 0.0;
+  for (int64_t c = 0; c < nchunk; c++) {
+    const int64_t col = c * kTdpC + lane;
+    tdp_park<LPW>(ta, ra, lane);
+    tdp_park<LPW>(td, rd, lane);
+    tdp_park<LPW>(tu, ru, lane);
+    __syncthreads();
+    if (c + 1 < nchunk) {
+      tdp_fetch<LPW>(ra, lo, line0, nl, L, col + kTdpC, 0.0);
+      tdp_fetch<LPW>(rd, di, line0, nl, L, col + kTdpC, 1.0);
+      tdp_fetch<LPW>(ru, up, line0, nl, L, col + kTdpC, 0.0);
+    }
+    if (lane < nl) {
+      const int cw = (int)((L - c * kTdpC) < kTdpC ? (L - c * kTdpC) : kTdpC);
+#pragma unroll 4
+      for (int j = 0; j < cw; j++) {
+        const double diag = td.v[lane][j] - uprev * ta.v[lane][j];
+        uprev = tu.v[lane][j] / diag;
+        td.v[lane][j] = diag;
+        tu.v[lane][j] = uprev;
+      }
+    }
+    __syncthreads();
+    tdp_flush<LPW>(td, dd, line0, nl, L, col, lane);
+    tdp_flush<LPW>(tu, ud, line0, nl, L, col, lane);
+    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_tdp_apply(const double *__restrict__ lo,
-                                                       const double *__restrict__ dd,
-                                                       const double *__restrict__ ud,
-                                                       const double *__restrict__ sol,
-                                                       double *__restrict__ out, int64_t nlines,
-                                                       int64_t L) {
-  const int64_t line = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (line >= nlines) return;
-  const int64_t b = line * L;
-  double prev = sol[b] / dd[b];
-  out[b] = prev;
-  for (int64_t j = 1; j < L; j++) {
-    prev = (sol[b + j] - prev * lo[b + j]) / dd[b + j];
-    out[b + j] = prev;
+// out = M^-1 sol for every line (include/solver.hpp:255-271: forward
+// elimination, then back substitution).  sol and out may be the same array.
+template <int LPW>
+__global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ lo,
+                                                      const double *__restrict__ dd,
+                                                      const double *__restrict__ ud,
+                                                      const double *sol, double *out,
+                                                      int64_t nlines, int64_t L) {
+  __shared__ TdpTile<LPW> ts, ta, td;
+  const int lane = threadIdx.x;
+  const int64_t line0 = (int64_t)blockIdx.x * LPW;
+  const int nl = (int)((nlines - line0) < LPW ? (nlines - line0) : LPW);
+  const int64_t nchunk = (L + kTdpC - 1) / kTdpC;
+  double rs[LPW], ra[LPW], rd[LPW];
+  tdp_fetch<LPW>(rs, sol, line0, nl, L, lane, 0.0);
+  tdp_fetch<LPW>(ra, lo, line0, nl, L, lane, 0.0);
+  tdp_fetch<LPW>(rd, dd, line0, nl, L, lane, 1.0);
+  if (lane == 0) {
+    // no predecessor: y_0 = (s_0 - (+0)(+0)) / d_0 = s_0 / d_0 exactly
+#pragma unroll
+    for (int i = 0; i < LPW; i++) ra[i] = 0.0;
   }
-  for (int64_t j = L - 2; j >= 0; j--) {
-    prev = out[b + j] - prev * ud[b + j];
-    out[b + j] = prev;
+  double prev = 0.0;
+  for (int64_t c = 0; c < nchunk; c++) {
+    const int64_t col = c * kTdpC + lane;
+    tdp_park<LPW>(ts, rs, lane);
+    tdp_park<LPW>(ta, ra, lane);
+    tdp_park<LPW>(td, rd, lane);
+    __syncthreads();
+    if (c + 1 < nchunk) {
+      tdp_fetch<LPW>(rs, sol, line0, nl, L, col + kTdpC, 0.0);
+      tdp_fetch<LPW>(ra, lo, line0, nl, L, col + kTdpC, 0.0);
+      tdp_fetch<LPW>(rd, dd, line0, nl, L, col + kTdpC, 1.0);
+    }
+    if (lane < nl) {
+      const int cw = (int)((L - c * kTdpC) < kTdpC ? (L - c * kTdpC) : kTdpC);
+      prev = tdp_walk_forward<LPW>(ts, ta, td, lane, cw, prev);
+    }
+    __syncthreads();
+    tdp_flush<LPW>(ts, out, line0, nl, L, col, lane);
+    __syncthreads();
+  }
+  // back substitution: element L-1 keeps its forward value (= prev); walk the
+  // chunks in reverse
+  tdp_fetch<LPW>(rs, out, line0, nl, L, (nchunk - 1) * kTdpC + lane, 0.0);
+  tdp_fetch<LPW>(ra, ud, line0, nl, L, (nchunk - 1) * kTdpC + lane, 0.0);
+  for (int64_t c = nchunk - 1; c >= 0; c--) {
+    const int64_t col = c * kTdpC + lane;
+    tdp_park<LPW>(ts, rs, lane);
+    tdp_park<LPW>(ta, ra, lane);
+    __syncthreads();
+    if (c > 0) {
+      tdp_fetch<LPW>(rs, out, line0, nl, L, col - kTdpC, 0.0);
+      tdp_fetch<LPW>(ra, ud, line0, nl, L, col - kTdpC, 0.0);
+    }
+    if (lane < nl) {
+      const int cw = (int)((L - c * kTdpC) < kTdpC ? (L - c * kTdpC) : kTdpC);
+      // the last chunk starts one element lower and therefore never takes the blocked walk
+      const int jtop = (c == nchunk - 1) ? cw - 2 : cw - 1;
+      prev = tdp_walk_backward<LPW>(ts, ta, lane, jtop, prev);
+    }
+    __syncthreads();
+    tdp_flush<LPW>(ts, out, line0, nl, L, col, lane);
+    __syncthreads();
   }
 }
 
@@ -979,16 +1179,53 @@ void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y
   hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n);
 }
 
+// lines per wavefront: the largest power of two <= 16 that still leaves about
+// two wavefronts per compute unit
+static int tdp_lines_per_wave(int64_t nlines) {
+  static const int forced = [] {
+    const char *e = getenv("KRY_TDP_LPW");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
+  int lpw = 16;
+  while (lpw > 1 && (nlines + lpw - 1) / lpw < 512) lpw >>= 1;
+  return lpw;
+}
+
+template <int LPW>
+static void launch_tdp_factor_t(hipStream_t st, const double *lo, const double *di, const double *up,
+                                double *dd, double *ud, int64_t nlines, int64_t L) {
+  const int g = (int)((nlines + LPW - 1) / LPW);
+  hipLaunchKernelGGL(k_tdp_factor<LPW>, dim3(g), dim3(kTdpC), 0, st, lo, di, up, dd, ud, nlines, L);
+}
+
+template <int LPW>
+static void launch_tdp_apply_t(hipStream_t st, const double *lo, const double *dd, const double *ud,
+                               const double *sol, double *out, int64_t nlines, int64_t L) {
+  const int g = (int)((nlines + LPW - 1) / LPW);
+  hipLaunchKernelGGL(k_tdp_apply<LPW>, dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L);
+}
+
 void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const double *up,
                        double *dd, double *ud, int64_t nlines, int64_t L) {
-  const int g = (int)((nlines + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_tdp_factor, dim3(g), dim3(kBlock), 0, st, lo, di, up, dd, ud, nlines, L);
+  switch (tdp_lines_per_wave(nlines)) {
+    case 16: launch_tdp_factor_t<16>(st, lo, di, up, dd, ud, nlines, L); break;
+    case 8: launch_tdp_factor_t<8>(st, lo, di, up, dd, ud, nlines, L); break;
+    case 4: launch_tdp_factor_t<4>(st, lo, di, up, dd, ud, nlines, L); break;
+    case 2: launch_tdp_factor_t<2>(st, lo, di, up, dd, ud, nlines, L); break;
+    default: launch_tdp_factor_t<1>(st, lo, di, up, dd, ud, nlines, L); break;
+  }
 }
 
 void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const double *ud,
                       const double *sol, double *out, int64_t nlines, int64_t L) {
-  const int g = (int)((nlines + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_tdp_apply, dim3(g), dim3(kBlock), 0, st, lo, dd, ud, sol, out, nlines, L);
+  switch (tdp_lines_per_wave(nlines)) {
+    case 16: launch_tdp_apply_t<16>(st, lo, dd, ud, sol, out, nlines, L); break;
+    case 8: launch_tdp_apply_t<8>(st, lo, dd, ud, sol, out, nlines, L); break;
+    case 4: launch_tdp_apply_t<4>(st, lo, dd, ud, sol, out, nlines, L); break;
+    case 2: launch_tdp_apply_t<2>(st, lo, dd, ud, sol, out, nlines, L); break;
+    default: launch_tdp_apply_t<1>(st, lo, dd, ud, sol, out, nlines, L); break;
+  }
 }
 
 void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col,
