@@ -53,9 +53,11 @@ enum kry_gmres_flags {
   KRY_GMRES_PLAIN = 0,
   KRY_GMRES_TDP = 1,           /* GMRESTDPSolver: tridiagonal right preconditioner   */
   KRY_GMRES_FIXED_PRECOND = 2, /* opt-in, not in the reference: return M^-1 u        */
-  KRY_GMRES_ORTH_CGS2 = 4      /* opt-in: classical Gram-Schmidt applied twice with
-                                  batched dot products instead of the reference's
-                                  modified Gram-Schmidt                             */
+  KRY_GMRES_EXTENDED = 8       /* opt-in, not in the reference: restarted GMRES(m)
+                                  with Givens-rotation least squares and a residual
+                                  monitor on the device (see kry_gmres_set_tolerance);
+                                  with KRY_GMRES_TDP the preconditioner is applied to
+                                  the result, i.e. proper right preconditioning      */
 };
 
 /* Message of the last failure on the calling thread ("" if none). */
@@ -156,6 +158,20 @@ int kry_gmres_set_mgs_block(kry_gmres *g, int k);
 int kry_gmres_get_mgs_block(const kry_gmres *g);
 int64_t kry_gmres_size(const kry_gmres *g);
 int kry_gmres_iterations(const kry_gmres *g);
+/* KRY_GMRES_EXTENDED only; no counterpart in the reference, whose solve always
+ * runs num_iters Arnoldi steps from x0 = 0 and solves the normal equations
+ * (include/solver.hpp:124-161).  A solve stops as soon as the residual norm
+ * ||b - A x|| <= rtol * ||b|| (measured through the rotated Hessenberg system,
+ * checked after every Arnoldi step on the device without a host round trip)
+ * and restarts from the current iterate after num_iters steps, at most
+ * max_cycles cycles.  Defaults: rtol = 1e-10, max_cycles = 20.  The host reads
+ * the solver state once per cycle. */
+int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles);
+/* Outcome of the last extended solve: Arnoldi steps over all cycles, cycles
+ * started, whether the tolerance was met, final residual norm / ||b||.
+ * Any pointer may be NULL. */
+int kry_gmres_last_stats(kry_gmres *g, int *iterations, int *cycles, int *converged,
+                         double *rel_residual);
 /* Kernel-level timing hooks for the benchmark: algorithmic bytes moved by the
  * kernels of one full cycle, per class (see kry_kernel_class). */
 enum kry_kernel_class {

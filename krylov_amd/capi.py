@@ -16,7 +16,7 @@ _vpp = C.POINTER(C.c_void_p)
 OK = 0
 FIELD_T, FIELD_U, FIELD_V = 0, 1, 2
 BOTTOM, TOP, LEFT, RIGHT = 0, 1, 2, 3
-GMRES_PLAIN, GMRES_TDP, GMRES_FIXED_PRECOND, GMRES_ORTH_CGS2 = 0, 1, 2, 4
+GMRES_PLAIN, GMRES_TDP, GMRES_FIXED_PRECOND, GMRES_EXTENDED = 0, 1, 2, 8
 K_SPMV, K_MGS, K_MGS_PART, K_MGS_LAST, K_NORMALIZE, K_COMBINE, K_PRECOND, K_ASSEMBLY, K_OTHER, K_COUNT = range(10)
 K_NAMES = ["spmv_dots", "mgs_block_full", "mgs_block_part", "mgs_last", "normalize", "combine", "precond", "assembly",
            "small_solve"]
@@ -57,6 +57,8 @@ SIGNATURES = {
     "kry_gmres_result_device": (_vp, [_vp]),
     "kry_gmres_set_mgs_block": (C.c_int, [_vp, C.c_int]),
     "kry_gmres_get_mgs_block": (C.c_int, [_vp]),
+    "kry_gmres_set_tolerance": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "kry_gmres_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "kry_gmres_size": (C.c_int64, [_vp]),
     "kry_gmres_iterations": (C.c_int, [_vp]),
     "kry_gmres_cycle_bytes": (C.c_int, [_vp, _vp, _dp, C.POINTER(C.c_int)]),

@@ -142,6 +142,14 @@ struct kry_gmres {
   double *dd = nullptr, *ud = nullptr;
   int64_t nlines = 0, L = 0;
   bool tdp_ready = false;
+  // restarted solver with residual monitor (KRY_GMRES_EXTENDED)
+  double rtol = 1e-10;
+  int max_cycles = 20;
+  ExtState *ext = nullptr;    // device
+  ExtState *ext_h = nullptr;  // pinned
+  double *R = nullptr;        // (m+1) x m rotated Hessenberg | cs (m) | sn (m) | gv (m+1)
+  int last_iters = 0, last_cycles = 0, last_converged = 0;
+  double last_relres = 0.0;
 };
 
 struct kry_ie {
@@ -514,6 +522,17 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   if (st == KRY_OK) st = dev_alloc(&g->beta, 1);
   if (st == KRY_OK) st = dev_alloc(&g->y, m);
   if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 2 * m);
+  if (st == KRY_OK && (flags & KRY_GMRES_EXTENDED)) {
+    st = dev_alloc(&g->R, (int64_t)(m + 1) * m + 3 * (int64_t)m + 1);
+    if (st == KRY_OK && hipMalloc((void **)&g->ext, sizeof(ExtState)) != hipSuccess)
+      st = fail(KRY_ERR_HIP, "hipMalloc of the solver state failed");
+    if (st == KRY_OK && hipHostMalloc((void **)&g->ext_h, sizeof(ExtState)) != hipSuccess)
+      st = fail(KRY_ERR_HIP, "hipHostMalloc of the solver state failed");
+    if (st == KRY_OK) {
+      (void)hipMemsetAsync(g->ext, 0, sizeof(ExtState), ctx->stream);
+      (void)hipMemsetAsync(g->R, 0, sizeof(double) * ((size_t)(m + 1) * m + 3 * (size_t)m + 1), ctx->stream);
+    }
+  }
   if (st == KRY_OK && (flags & KRY_GMRES_TDP)) {
     st = dev_alloc(&g->z, g->ld);
     if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
@@ -552,8 +571,10 @@ void kry_gmres_destroy(kry_gmres *g) {
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
                     g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
-                    g->dd, g->ud};
+                    g->dd, g->ud, g->R};
   for (double *p : bufs) (void)hipFree(p);
+  if (g->ext) (void)hipFree(g->ext);
+  if (g->ext_h) (void)hipHostFree(g->ext_h);
   if (g->own_tri) {
     (void)hipFree(g->lo);
     (void)hipFree(g->di);
@@ -572,6 +593,25 @@ int kry_gmres_set_mgs_block(kry_gmres *g, int k) {
 }
 
 int kry_gmres_get_mgs_block(const kry_gmres *g) { return g ? g->kblock : 0; }
+
+int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
+  if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!(g->flags & KRY_GMRES_EXTENDED)) return fail(KRY_ERR_STATE, "solver was created without KRY_GMRES_EXTENDED");
+  if (!(rtol >= 0.0) || max_cycles < 1) return fail(KRY_ERR_INVALID, "rtol must be >= 0 and max_cycles >= 1");
+  g->rtol = rtol;
+  g->max_cycles = max_cycles;
+  return KRY_OK;
+}
+
+int kry_gmres_last_stats(kry_gmres *g, int *iterations, int *cycles, int *converged, double *rel_residual) {
+  if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!(g->flags & KRY_GMRES_EXTENDED)) return fail(KRY_ERR_STATE, "solver was created without KRY_GMRES_EXTENDED");
+  if (iterations) *iterations = g->last_iters;
+  if (cycles) *cycles = g->last_cycles;
+  if (converged) *converged = g->last_converged;
+  if (rel_residual) *rel_residual = g->last_relres;
+  return KRY_OK;
+}
 
 int64_t kry_gmres_size(const kry_gmres *g) { return g ? g->n : 0; }
 int kry_gmres_iterations(const kry_gmres *g) { return g ? g->m : 0; }
@@ -642,8 +682,11 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   return launch_ok("initial_subspace");
 }
 
-// One Arnoldi step with the fused modified Gram-Schmidt chain.
+// One Arnoldi step with the fused modified Gram-Schmidt chain.  In the
+// restarted solver every kernel of the step is predicated on the device flag
+// that the residual monitor raises.
 static int arnoldi_async(kry_gmres *g, kry_op *op) {
+  LaunchPredicate pred((g->flags & KRY_GMRES_EXTENDED) && g->ext ? &g->ext->stop : nullptr);
   if (g->nvec < 1) return fail(KRY_ERR_STATE, "add_arnoldi before initial_subspace");
   const int j = g->nvec - 1;
   if (j >= g->m) return fail(KRY_ERR_STATE, "subspace is full (%d vectors for num_iters = %d)", g->nvec, g->m);
@@ -702,7 +745,84 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   return launch_ok("add_arnoldi");
 }
 
+// Restarted GMRES(m) with Givens rotations and a residual monitor on the
+// device.  One host round trip per cycle (to decide about a restart), none
+// inside a cycle: after convergence the remaining kernels of the cycle return
+// immediately.  Returns with the result in g->vars and the stream idle.
+static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double *x_dev) {
+  hipStream_t st = g->ctx->stream;
+  const int m = g->m;
+  const int64_t n = g->n;
+  double *R = g->R, *cs = R + (int64_t)(m + 1) * m, *sn = cs + m, *gv = sn + m;
+  if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
+  HIPCHK(hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)n, st));
+  g->last_iters = 0;
+  g->last_cycles = 0;
+  g->last_converged = 0;
+  g->last_relres = 0.0;
+  for (int cycle = 0; cycle < g->max_cycles; cycle++) {
+    if (cycle == 0) {
+      KCHK(initial_subspace_async(g, b_dev));
+    } else {
+      // v_0 = r / ||r||,  r = b - A x
+      if (g->halo_row > 0) KCHK(comm_halo(g->ctx, g->vars, g->halo_row, n));
+      int np = 0;
+      {
+        ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
+        op_apply_async(op, g->vars, g->w, 0, nullptr, 0, nullptr, nullptr, g->halo_row > 0);
+      }
+      ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
+      launch_sub_nrm2(st, b_dev, g->w, g->w, n, g->parts, &np);
+      const double *pin = g->parts;
+      KCHK(finish_parts(g, &pin, 1, &np));
+      launch_scale_from(st, g->w, basis(g, 0), pin, np, n, g->beta);
+      g->nvec = 1;
+    }
+    {
+      ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+      launch_ext_begin(st, g->beta, g->ext, gv, m, cycle == 0, g->rtol);
+    }
+    HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(m + 1) * m, st));
+    for (int j = 0; j < m; j++) {
+      KCHK(arnoldi_async(g, op));
+      ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+      launch_givens(st, g->H, m, j, R, cs, sn, gv, g->ext);
+    }
+    {
+      ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+      launch_ext_solve(st, R, gv, m, g->ext, g->y);
+    }
+    if (g->flags & KRY_GMRES_TDP) {
+      // x += M^-1 (V y)
+      {
+        ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
+        launch_combine(st, basis(g, 0), g->ld, g->y, m, g->w, n, &g->ext->iters, false);
+      }
+      {
+        ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
+        launch_tdp_apply(st, g->lo, g->dd, g->ud, g->w, g->w, g->nlines, g->L);
+      }
+      ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
+      launch_add(st, g->vars, g->w, n);
+    } else {
+      ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
+      launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true);
+    }
+    KCHK(launch_ok("extended solve"));
+    HIPCHK(hipMemcpyAsync(g->ext_h, g->ext, sizeof(ExtState), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    g->last_cycles = cycle + 1;
+    g->last_iters += g->ext_h->iters;
+    g->last_converged = g->ext_h->converged;
+    g->last_relres = g->ext_h->beta0 > 0.0 ? g->ext_h->res / g->ext_h->beta0 : g->ext_h->res;
+    if (g->ext_h->stop) break;  // tolerance met, or the iteration broke down (NaN)
+  }
+  if (x_dev) HIPCHK(hipMemcpyAsync(x_dev, g->vars, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  return KRY_OK;
+}
+
 static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_dev) {
+  if (g->flags & KRY_GMRES_EXTENDED) return solve_extended(g, op, b_dev, x_dev);
   hipStream_t st = g->ctx->stream;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   KCHK(initial_subspace_async(g, b_dev));
@@ -1075,7 +1195,8 @@ static int ie_step_body(kry_ie *ie, double dt, bool force_upload) {
 static int ie_step_async(kry_ie *ie, double dt) {
   if (!ie->solver) return fail(KRY_ERR_STATE, "step object was created without a solver");
   hipStream_t st = ie->ctx->stream;
-  if (!ie->use_graph || ie->ctx->nranks > 1) {
+  // the restarted solver reads its state on the host between cycles: no capture
+  if (!ie->use_graph || ie->ctx->nranks > 1 || (ie->solver->flags & KRY_GMRES_EXTENDED)) {
     KCHK(ie_step_body(ie, dt, false));
   } else {
     if (!ie->graph_exec || ie->graph_dt != dt) {

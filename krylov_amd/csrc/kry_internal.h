@@ -21,6 +21,32 @@ struct Bands {
   const double *w, *s, *c, *n, *e;
 };
 
+// Device-resident state of the restarted solver with residual monitor.
+struct ExtState {
+  double tol_abs;  // rtol * ||b||, fixed by the first cycle
+  double res;      // residual norm of the best iterate of the current cycle
+  double beta0;    // ||b||
+  int stop;        // non-zero: the remaining iteration kernels of the cycle are no-ops
+  int iters;       // Arnoldi steps completed in the current cycle
+  int converged;   // res <= tol_abs was observed
+  int pad;
+};
+
+// While an object of this type is alive, the iteration kernels launched by the
+// calling thread (operator apply, Gram-Schmidt sweeps, normalisation, line
+// solves, partial-sum collapse) receive `stop` and return at once when *stop
+// is non-zero on the device.
+class LaunchPredicate {
+ public:
+  explicit LaunchPredicate(const int *stop);
+  ~LaunchPredicate();
+  LaunchPredicate(const LaunchPredicate &) = delete;
+  LaunchPredicate &operator=(const LaunchPredicate &) = delete;
+
+ private:
+  const int *saved_;
+};
+
 // ---- launchers (all asynchronous on `st`) ---------------------------------
 int grid_for(int64_t items);
 
@@ -53,9 +79,24 @@ void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *p
 // Doolittle LU, in the reference's loop order.  work: 3*m*m + 2*m doubles.
 void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,
                         double *work);
-// x[k] = sum_i y[i] * V[i*ld + k], accumulated in order i = 0..m-1 from 0.0
+// x[k] = sum_i y[i] * V[i*ld + k], accumulated in order i = 0..m-1 from 0.0 (or
+// from x[k] with accumulate); count != nullptr: only the first min(m, *count) terms
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m,
-                    double *x, int64_t n);
+                    double *x, int64_t n, const int *count = nullptr, bool accumulate = false);
+// x += w
+void launch_add(hipStream_t st, double *x, const double *w, int64_t n);
+// out = a - b; part[b] = sum over block b of out[k]^2 (out may be b)
+void launch_sub_nrm2(hipStream_t st, const double *a, const double *b, double *out, int64_t n,
+                     double *part, int *nparts);
+
+// Restarted solver with residual monitor: cycle start, Givens update of
+// column j (R: (m+1) x m rotated Hessenberg, cs/sn: m, gv: m+1), cycle end.
+void launch_ext_begin(hipStream_t st, const double *beta, ExtState *state, double *gv, int m, bool first,
+                      double rtol);
+void launch_givens(hipStream_t st, const double *H, int m, int j, double *R, double *cs, double *sn,
+                   double *gv, ExtState *state);
+void launch_ext_solve(hipStream_t st, const double *R, const double *gv, int m, const ExtState *state,
+                      double *y);
 
 // Tridiagonal preconditioner made of independent lines of length L.
 void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const double *up,

@@ -19,6 +19,16 @@
 
 namespace kry {
 
+// Device flag that turns the iteration kernels launched by this thread into
+// no-ops once it is non-zero (see LaunchPredicate in kry_internal.h).
+static thread_local const int *t_stop = nullptr;
+
+LaunchPredicate::LaunchPredicate(const int *stop) : saved_(t_stop) { t_stop = stop; }
+LaunchPredicate::~LaunchPredicate() { t_stop = saved_; }
+
+// true when the solver this launch belongs to has already met its tolerance
+__device__ __forceinline__ bool stopped(const int *__restrict__ stop) { return stop != nullptr && *stop != 0; }
+
 int grid_for(int64_t items) {
   int64_t b = (items + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -113,7 +123,8 @@ __global__ __launch_bounds__(kBlock) void k_fill(double *__restrict__ x, double 
 // tot[q] = sum_i part[q * np + i]: collapses the per-workgroup partial sums to
 // one value per quantity so that ranks can all-reduce a handful of doubles.
 __global__ __launch_bounds__(kBlock) void k_reduce_parts(const double *__restrict__ part, int nq, int np,
-                                                          double *__restrict__ tot) {
+                                                          double *__restrict__ tot, const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int q = wv; q < nq; q += kBlock / 64) {
     double a = 0.0;
@@ -151,7 +162,9 @@ __global__ __launch_bounds__(kBlock) void k_nrm2_part(const double *__restrict__
 __global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict__ src,
                                                         double *__restrict__ dst,
                                                         const double *__restrict__ part, int np,
-                                                        int64_t n, double *__restrict__ out) {
+                                                        int64_t n, double *__restrict__ out,
+                                                        const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   __shared__ double s[kBlock / 64];
   const double nrm = sqrt(sum_parts(part, np, s));
   if (blockIdx.x == 0 && threadIdx.x == 0 && out) *out = nrm;
@@ -208,7 +221,8 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
                                                        const double *__restrict__ part_in, int np_in,
                                                        double *__restrict__ part_out,
                                                        double *__restrict__ hout, int hstride,
-                                                       int64_t n) {
+                                                       int64_t n, const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   constexpr int NQI = nred(KP);
   constexpr int NQO = NORM ? 1 : nred(KC);
   __shared__ double tot[NQI];
@@ -309,16 +323,24 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
 
 // x = sum_i y_i v_i, accumulated per element in the order i = 0..m-1 starting
 // from 0.0 with a separate multiply and add (include/solver.hpp:153-159).
+// count (optional, device): only the first min(m, *count) vectors take part;
+// accumulate: start from the current x instead of 0.0.
 __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V, int64_t ld,
                                                      const double *__restrict__ y, int m,
-                                                     double *__restrict__ x, int64_t n) {
+                                                     double *__restrict__ x, int64_t n,
+                                                     const int *__restrict__ count, int accumulate) {
   __shared__ double ys[kMaxM];
+  if (count != nullptr) {
+    const int c = *count;
+    if (c < m) m = c;
+  }
   for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = y[i];
   __syncthreads();
   const int64_t n2 = n >> 1;
   d2 *x2 = reinterpret_cast<d2 *>(x);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     d2 acc = {0.0, 0.0};
+    if (accumulate) acc = x2[i];
 #pragma unroll 8
     for (int k = 0; k < m; k++) {
       const d2 v = ld_nt(reinterpret_cast<const d2 *>(V + (int64_t)k * ld) + i);
@@ -327,10 +349,140 @@ __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V
     st_nt(acc, &x2[i]);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    double acc = 0.0;
+    double acc = accumulate ? x[n - 1] : 0.0;
     for (int k = 0; k < m; k++) acc = acc + ys[k] * V[(int64_t)k * ld + n - 1];
     x[n - 1] = acc;
   }
+}
+
+// x += w
+__global__ __launch_bounds__(kBlock) void k_add(double *__restrict__ x, const double *__restrict__ w, int64_t n) {
+  const int64_t n2 = n >> 1;
+  d2 *x2 = reinterpret_cast<d2 *>(x);
+  const d2 *w2 = reinterpret_cast<const d2 *>(w);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock)
+    x2[i] = x2[i] + ld_nt(&w2[i]);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = x[n - 1] + w[n - 1];
+}
+
+// out = a - b and the per-workgroup partial sums of out^2 (restart residual)
+__global__ __launch_bounds__(kBlock) void k_sub_nrm2(const double *__restrict__ a, const double *b, double *out,
+                                                      int64_t n, double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  const int64_t n2 = n >> 1;
+  const d2 *a2 = reinterpret_cast<const d2 *>(a);
+  const d2 *b2 = reinterpret_cast<const d2 *>(b);
+  d2 *o2 = reinterpret_cast<d2 *>(out);
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    const d2 r = a2[i] - b2[i];
+    o2[i] = r;
+    acc = fma(r.x, r.x, acc);
+    acc = fma(r.y, r.y, acc);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double r = a[n - 1] - b[n - 1];
+    out[n - 1] = r;
+    acc = fma(r, r, acc);
+  }
+  const double t = block_sum(acc, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------
+// Restarted GMRES with a residual monitor (no counterpart in the reference,
+// whose cycle always runs num_iters steps and solves the normal equations):
+// the Hessenberg column of every Arnoldi step is reduced by Givens rotations
+// on the device, the rotated right-hand side gives the residual norm, and once
+// it meets the tolerance a device flag turns the remaining iteration kernels
+// of the cycle into no-ops - the host looks at the state once per cycle.
+// ---------------------------------------------------------------------------
+// Start of a cycle: g = (beta, 0, ..., 0); the first cycle fixes the absolute
+// tolerance rtol * ||b||.
+__global__ __launch_bounds__(64) void k_ext_begin(const double *__restrict__ beta, ExtState *__restrict__ st,
+                                                   double *__restrict__ gv, int m, int first, double rtol) {
+  for (int i = 1 + threadIdx.x; i <= m; i += 64) gv[i] = 0.0;
+  if (threadIdx.x == 0) {
+    const double b = *beta;
+    if (first) {
+      st->beta0 = b;
+      st->tol_abs = rtol * b;
+    }
+    gv[0] = b;
+    st->res = b;
+    st->iters = 0;
+    const bool done = b <= st->tol_abs;
+    st->converged = done ? 1 : 0;
+    st->stop = (done || !(b == b)) ? 1 : 0;
+  }
+}
+
+// Step j: apply the j earlier rotations to column j of H, form the new
+// rotation, update g; |g_{j+1}| is the residual norm of the best iterate.
+__global__ __launch_bounds__(64) void k_givens(const double *__restrict__ H, int m, int j,
+                                                double *__restrict__ R, double *__restrict__ cs,
+                                                double *__restrict__ sn, double *__restrict__ gv,
+                                                ExtState *__restrict__ st) {
+  if (st->stop != 0) return;
+  __shared__ double r[kMaxM + 1], c[kMaxM], s[kMaxM];
+  for (int i = threadIdx.x; i <= j + 1; i += 64) r[i] = H[(size_t)i * m + j];
+  for (int i = threadIdx.x; i < j; i += 64) {
+    c[i] = cs[i];
+    s[i] = sn[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < j; i++) {
+      const double t = c[i] * r[i] + s[i] * r[i + 1];
+      r[i + 1] = c[i] * r[i + 1] - s[i] * r[i];
+      r[i] = t;
+    }
+    const double a = r[j], b = r[j + 1];
+    const double d = sqrt(a * a + b * b);
+    double cc = 1.0, ss = 0.0;
+    if (d != 0.0) {
+      cc = a / d;
+      ss = b / d;
+    }
+    r[j] = cc * a + ss * b;
+    r[j + 1] = 0.0;
+    const double gj = gv[j];
+    const double gn = -(ss * gj);
+    gv[j] = cc * gj;
+    gv[j + 1] = gn;
+    cs[j] = cc;
+    sn[j] = ss;
+    const double res = fabs(gn);
+    st->res = res;
+    st->iters = j + 1;
+    if (res <= st->tol_abs) {
+      st->converged = 1;
+      st->stop = 1;
+    } else if (!(res == res)) {
+      st->stop = 1;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= j + 1; i += 64) R[(size_t)i * m + j] = r[i];
+}
+
+// End of a cycle: back substitution R y = g over the k = st->iters columns
+// that were completed; y[i >= k] = 0.
+__global__ __launch_bounds__(64) void k_ext_solve(const double *__restrict__ R, const double *__restrict__ gv,
+                                                   int m, const ExtState *__restrict__ st,
+                                                   double *__restrict__ y) {
+  __shared__ double ys[kMaxM];
+  const int k = st->iters;
+  for (int i = threadIdx.x; i < m; i += 64) ys[i] = 0.0;
+  __syncthreads();
+  for (int i = k - 1; i >= 0; i--) {
+    double a = 0.0;
+    for (int jj = i + 1 + threadIdx.x; jj < k; jj += 64) a = fma(R[(size_t)i * m + jj], ys[jj], a);
+    a = wave_sum(a);
+    if (threadIdx.x == 0) ys[i] = (gv[i] - a) / R[(size_t)i * m + i];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < m; i += 64) y[i] = ys[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -364,7 +516,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
                                                           const double *__restrict__ x,
                                                           double *__restrict__ y,
                                                           const double *__restrict__ cbase, int64_t ld,
-                                                          double *__restrict__ part) {
+                                                          double *__restrict__ part, const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
   double acc[NQ];
@@ -401,7 +554,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
                                                              const double *__restrict__ x,
                                                              double *__restrict__ y,
                                                              const double *__restrict__ cbase, int64_t ld,
-                                                             double *__restrict__ part) {
+                                                             double *__restrict__ part, const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
   const int64_t n2 = n >> 1;
@@ -474,7 +628,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__
                                                       const double *__restrict__ x,
                                                       double *__restrict__ y,
                                                       const double *__restrict__ cbase, int64_t ld,
-                                                      double *__restrict__ part) {
+                                                      double *__restrict__ part, const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
   double acc[NQ];
@@ -741,7 +896,9 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ 
                                                       const double *__restrict__ dd,
                                                       const double *__restrict__ ud,
                                                       const double *sol, double *out,
-                                                      int64_t nlines, int64_t L) {
+                                                      int64_t nlines, int64_t L,
+                                                      const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   __shared__ TdpTile<LPW> ts, ta, td;
   const int lane = threadIdx.x;
   const int64_t line0 = (int64_t)blockIdx.x * LPW;
@@ -1065,7 +1222,7 @@ void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, 
 void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
                        int nparts, int64_t n, double *out) {
   const int g = stream_grid(n >> 1, 4, 1024);
-  hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out);
+  hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out, t_stop);
 }
 
 template <int KC, bool HALO>
@@ -1081,9 +1238,9 @@ static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int
   }
   if (nparts) *nparts = g;
   if (vec)
-    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop);
   else
-    hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part);
+    hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop);
 }
 
 template <bool HALO>
@@ -1108,7 +1265,7 @@ void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, co
 }
 
 void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot) {
-  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, part, nq, np, tot);
+  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, part, nq, np, tot, t_stop);
 }
 
 template <int KC>
@@ -1117,7 +1274,7 @@ static void launch_spmv_csr_t(hipStream_t st, const int64_t *rowptr, const int32
                               double *part, int *nparts) {
   const int g = grid_for(n);
   if (nparts) *nparts = g;
-  hipLaunchKernelGGL((k_spmv_csr<KC>), dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, cbase, ld, part);
+  hipLaunchKernelGGL((k_spmv_csr<KC>), dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, cbase, ld, part, t_stop);
 }
 
 void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
@@ -1141,7 +1298,7 @@ static void launch_mgs_block_t(hipStream_t st, double *w, const double *pbase, c
   const int g = sweep_grid(n >> 1, streams, U);
   *np_out = g;
   hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, U>), dim3(g), dim3(kBlock), 0, st, w, pbase, cbase, ld,
-                     part_in, np_in, part_out, hout, hstride, n);
+                     part_in, np_in, part_out, hout, hstride, n, t_stop);
 }
 
 template <int KP>
@@ -1174,9 +1331,36 @@ void launch_small_solve(hipStream_t st, const double *H, const double *beta, int
 }
 
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x,
-                    int64_t n) {
+                    int64_t n, const int *count, bool accumulate) {
   const int g = grid_for((n + 1) / 2);
-  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n);
+  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n, count, accumulate ? 1 : 0);
+}
+
+void launch_add(hipStream_t st, double *x, const double *w, int64_t n) {
+  const int g = stream_grid((n + 1) >> 1, 1, 1024);
+  hipLaunchKernelGGL(k_add, dim3(g), dim3(kBlock), 0, st, x, w, n);
+}
+
+void launch_sub_nrm2(hipStream_t st, const double *a, const double *b, double *out, int64_t n,
+                     double *part, int *nparts) {
+  const int g = stream_grid((n + 1) >> 1, 1, 1024);
+  *nparts = g;
+  hipLaunchKernelGGL(k_sub_nrm2, dim3(g), dim3(kBlock), 0, st, a, b, out, n, part);
+}
+
+void launch_ext_begin(hipStream_t st, const double *beta, ExtState *state, double *gv, int m, bool first,
+                      double rtol) {
+  hipLaunchKernelGGL(k_ext_begin, dim3(1), dim3(64), 0, st, beta, state, gv, m, first ? 1 : 0, rtol);
+}
+
+void launch_givens(hipStream_t st, const double *H, int m, int j, double *R, double *cs, double *sn,
+                   double *gv, ExtState *state) {
+  hipLaunchKernelGGL(k_givens, dim3(1), dim3(64), 0, st, H, m, j, R, cs, sn, gv, state);
+}
+
+void launch_ext_solve(hipStream_t st, const double *R, const double *gv, int m, const ExtState *state,
+                      double *y) {
+  hipLaunchKernelGGL(k_ext_solve, dim3(1), dim3(64), 0, st, R, gv, m, state, y);
 }
 
 // lines per wavefront: the largest power of two <= 16 that still leaves about
@@ -1203,7 +1387,7 @@ template <int LPW>
 static void launch_tdp_apply_t(hipStream_t st, const double *lo, const double *dd, const double *ud,
                                const double *sol, double *out, int64_t nlines, int64_t L) {
   const int g = (int)((nlines + LPW - 1) / LPW);
-  hipLaunchKernelGGL(k_tdp_apply<LPW>, dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L);
+  hipLaunchKernelGGL(k_tdp_apply<LPW>, dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L, t_stop);
 }
 
 void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const double *up,

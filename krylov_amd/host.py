@@ -103,15 +103,29 @@ class Operator:
 class GMRESSolver:
     """GMRESSolver<m> (tdp=False) / GMRESTDPSolver<m> (tdp=True)."""
 
-    def __init__(self, ctx, n, m, tdp=False, fixed_preconditioning=False, handle=None):
+    def __init__(self, ctx, n, m, tdp=False, fixed_preconditioning=False, handle=None, extended=None):
+        """extended=(rtol, max_cycles): restarted GMRES(m) with Givens rotations
+        and a residual monitor instead of the reference's single fixed cycle."""
         self.ctx, self.n, self.m, self.tdp = ctx, n, m, tdp
         self._own = handle is None
         if handle is None:
-            flags = (GMRES_TDP if tdp else 0) | (GMRES_FIXED_PRECOND if fixed_preconditioning else 0)
+            flags = ((GMRES_TDP if tdp else 0) | (GMRES_FIXED_PRECOND if fixed_preconditioning else 0)
+                     | (capi.GMRES_EXTENDED if extended is not None else 0))
             h = C.c_void_p()
             check(capi.lib().kry_gmres_create(ctx.h, n, m, flags, C.byref(h)))
             handle = h
         self.h = handle
+        if extended is not None:
+            self.set_tolerance(*extended)
+
+    def set_tolerance(self, rtol, max_cycles):
+        check(capi.lib().kry_gmres_set_tolerance(self.h, float(rtol), int(max_cycles)))
+
+    def last_stats(self):
+        """(Arnoldi steps, cycles, converged, residual / ||b||) of the last extended solve."""
+        it, cy, cv, rr = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(capi.lib().kry_gmres_last_stats(self.h, C.byref(it), C.byref(cy), C.byref(cv), C.byref(rr)))
+        return it.value, cy.value, bool(cv.value), rr.value
 
     def initial_subspace(self, b):
         b, pb = _d(b)
@@ -184,9 +198,11 @@ class ImplicitEuler:
 
     def __init__(self, ctx, corner1, corner2, cx, cy, init, params, bcs, m, tdp=False,
                  fixed_preconditioning=False, use_graph=False, bc_time_dependent=True, mgs_block=None,
-                 row_range=None):
+                 row_range=None, extended=None):
         """row_range=(begin, end): own only these padded rows of the mesh (one
-        rank of a row-block decomposition; the context needs collectives)."""
+        rank of a row-block decomposition; the context needs collectives).
+        extended=(rtol, max_cycles): solve every step with the restarted,
+        residual-monitored GMRES(m) instead of the reference's fixed cycle."""
         L = capi.lib()
         self.ctx, self.cx, self.cy, self.m, self.tdp = ctx, cx, cy, m, tdp
         self.row_range = (0, cx + 2) if row_range is None else (int(row_range[0]), int(row_range[1]))
@@ -213,7 +229,8 @@ class ImplicitEuler:
         T0, u0, v0 = init(xs[:, None], ys[None, :])
         T0, u0, v0 = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (len(xs), cy)))
                       for a in (T0, u0, v0))
-        gflags = (GMRES_TDP if tdp else 0) | (GMRES_FIXED_PRECOND if fixed_preconditioning else 0)
+        gflags = ((GMRES_TDP if tdp else 0) | (GMRES_FIXED_PRECOND if fixed_preconditioning else 0)
+                  | (capi.GMRES_EXTENDED if extended is not None else 0))
         h = C.c_void_p()
         check(L.kry_ie_create_slab(ctx.h, corner1[0], corner1[1], corner2[0], corner2[1], cx, cy, r0, r1,
                                    T0.ctypes.data_as(_dp), u0.ctypes.data_as(_dp), v0.ctypes.data_as(_dp),
@@ -226,6 +243,8 @@ class ImplicitEuler:
             check(L.kry_ie_use_graph(h, 1))
         if mgs_block is not None and m > 0:
             check(L.kry_gmres_set_mgs_block(L.kry_ie_solver(h), mgs_block))
+        if extended is not None:
+            check(L.kry_gmres_set_tolerance(L.kry_ie_solver(h), float(extended[0]), int(extended[1])))
         self._bc_pushed = False
         self._push_bc_values(0.0)
         check(L.kry_ie_init_offdiag(h))

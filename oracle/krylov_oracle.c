@@ -273,6 +273,11 @@ typedef struct orc_gmres {
   double *lu_work;
   double *sys, *rhs, *y;
   double *tdiags, *td_vars, *td_udiag;
+  /* restarted solver with residual monitor (not in the reference) */
+  int ext_on, ext_max_cycles;
+  double ext_rtol;
+  int last_iters, last_cycles, last_converged;
+  double last_relres;
 } orc_gmres;
 
 ORC_API orc_gmres *orc_gmres_create(long n, int m, int tdp) {
@@ -374,10 +379,14 @@ ORC_API double orc_gmres_add_arnoldi(orc_gmres *g, const orc_op *op) {
  * (:290-293) first rebuilds the tridiagonal preconditioner.  The returned
  * vector is the plain combination of the basis vectors: for the
  * preconditioned solver the reference does not apply M^-1 to it. */
+ORC_API const double *orc_gmres_solve_extended(orc_gmres *g, const orc_op *op,
+                                               const double *sol);
+
 ORC_API const double *orc_gmres_solve(orc_gmres *g, const orc_op *op,
                                       const double *sol) {
   const long n = g->n;
   const int m = g->m;
+  if (g->ext_on) return orc_gmres_solve_extended(g, op, sol);
   if (g->tdp) orc_gmres_assemble_preconditioner(g, op);
   const double beta = orc_gmres_initial_subspace(g, sol);
   for (int p = 0; p < (m + 1) * m; p++) g->H[p] = 0.0;
@@ -411,6 +420,130 @@ ORC_API const double *orc_gmres_solve(orc_gmres *g, const orc_op *op,
     orc_sparse_tridiag_solve(g->tdiags, g->vars, g->td_vars, g->td_udiag, n);
     memcpy(g->vars, g->td_vars, sizeof(double) * (size_t)n);
   }
+  return g->vars;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Restarted GMRES(m) with Givens-rotation least squares and a residual      */
+/* monitor.  NOT part of the reference (its solve is the fixed cycle above); */
+/* this is the CPU statement of the device library's extended mode, used to  */
+/* check that mode's iteration counts and solutions.  The Arnoldi step is    */
+/* the reference's (add_arnoldi / gram_schmidt above); with the tridiagonal  */
+/* preconditioner the result is x = M^-1 (V y), proper right                 */
+/* preconditioning.                                                          */
+/* ------------------------------------------------------------------------ */
+ORC_API void orc_gmres_set_extended(orc_gmres *g, int on, double rtol, int max_cycles) {
+  g->ext_on = on;
+  g->ext_rtol = rtol;
+  g->ext_max_cycles = max_cycles;
+}
+
+ORC_API void orc_gmres_last_stats(const orc_gmres *g, int *iters, int *cycles,
+                                  int *converged, double *relres) {
+  *iters = g->last_iters;
+  *cycles = g->last_cycles;
+  *converged = g->last_converged;
+  *relres = g->last_relres;
+}
+
+ORC_API const double *orc_gmres_solve_extended(orc_gmres *g, const orc_op *op,
+                                               const double *sol) {
+  const long n = g->n;
+  const int m = g->m;
+  double *R = (double *)calloc((size_t)(m + 1) * m, sizeof(double));
+  double *cs = (double *)calloc((size_t)m, sizeof(double));
+  double *sn = (double *)calloc((size_t)m, sizeof(double));
+  double *gv = (double *)calloc((size_t)m + 1, sizeof(double));
+  double *col = (double *)calloc((size_t)m + 1, sizeof(double));
+  double *r = (double *)malloc(sizeof(double) * (size_t)n);
+  double *u = (double *)malloc(sizeof(double) * (size_t)n);
+  double beta0 = 0.0, tol = 0.0, res = 0.0;
+  if (g->tdp) orc_gmres_assemble_preconditioner(g, op);
+  for (long k = 0; k < n; k++) g->vars[k] = 0.0;
+  g->last_iters = 0;
+  g->last_cycles = 0;
+  g->last_converged = 0;
+  for (int cycle = 0; cycle < g->ext_max_cycles; cycle++) {
+    int stop = 0, iters = 0;
+    if (cycle == 0) {
+      memcpy(r, sol, sizeof(double) * (size_t)n);
+    } else {
+      orc_op_apply(op, g->next, g->vars);
+      for (long k = 0; k < n; k++) r[k] = sol[k] - g->next[k];
+    }
+    const double beta = orc_gmres_initial_subspace(g, r); /* v_0 = r / ||r|| */
+    if (cycle == 0) {
+      beta0 = beta;
+      tol = g->ext_rtol * beta;
+    }
+    res = beta;
+    for (int i = 0; i <= m; i++) gv[i] = 0.0;
+    gv[0] = beta;
+    if (beta <= tol) {
+      g->last_converged = 1;
+      stop = 1;
+    } else if (!(beta == beta)) {
+      stop = 1;
+    }
+    for (int p = 0; p < (m + 1) * m; p++) g->H[p] = 0.0;
+    for (int j = 0; j < m && !stop; j++) {
+      orc_gmres_add_arnoldi(g, op);
+      for (int i = 0; i <= j + 1; i++) col[i] = g->H[i * m + j];
+      for (int i = 0; i < j; i++) {
+        const double t = cs[i] * col[i] + sn[i] * col[i + 1];
+        col[i + 1] = cs[i] * col[i + 1] - sn[i] * col[i];
+        col[i] = t;
+      }
+      const double a = col[j], b = col[j + 1];
+      const double d = sqrt(a * a + b * b);
+      double cc = 1.0, ss = 0.0;
+      if (d != 0.0) {
+        cc = a / d;
+        ss = b / d;
+      }
+      col[j] = cc * a + ss * b;
+      col[j + 1] = 0.0;
+      const double gj = gv[j];
+      const double gn = -(ss * gj);
+      gv[j] = cc * gj;
+      gv[j + 1] = gn;
+      cs[j] = cc;
+      sn[j] = ss;
+      for (int i = 0; i <= j + 1; i++) R[i * m + j] = col[i];
+      res = fabs(gn);
+      iters = j + 1;
+      if (res <= tol) {
+        g->last_converged = 1;
+        stop = 1;
+      } else if (!(res == res)) {
+        stop = 1;
+      }
+    }
+    /* back substitution over the completed columns */
+    for (int i = 0; i < m; i++) g->y[i] = 0.0;
+    for (int i = iters - 1; i >= 0; i--) {
+      double acc = 0.0;
+      for (int jj = i + 1; jj < iters; jj++) acc += R[i * m + jj] * g->y[jj];
+      g->y[i] = (gv[i] - acc) / R[i * m + i];
+    }
+    for (long k = 0; k < n; k++) u[k] = 0.0;
+    for (int i = 0; i < iters; i++) {
+      const double *dim = g->V + (size_t)i * n;
+      const double sc = g->y[i];
+      for (long k = 0; k < n; k++) u[k] += sc * dim[k];
+    }
+    if (g->tdp) {
+      orc_sparse_tridiag_solve(g->tdiags, u, g->td_vars, g->td_udiag, n);
+      for (long k = 0; k < n; k++) g->vars[k] += g->td_vars[k];
+    } else {
+      for (long k = 0; k < n; k++) g->vars[k] += u[k];
+    }
+    g->last_cycles = cycle + 1;
+    g->last_iters += iters;
+    if (stop) break;
+  }
+  g->last_relres = beta0 > 0.0 ? res / beta0 : res;
+  free(R); free(cs); free(sn); free(gv); free(col); free(r); free(u);
   return g->vars;
 }
 

@@ -69,6 +69,8 @@ def lib():
     sig("orc_gmres_assemble_preconditioner", None, _vp, _vp)
     sig("orc_gmres_add_arnoldi", C.c_double, _vp, _vp)
     sig("orc_gmres_solve", _dp, _vp, _vp, _dp)
+    sig("orc_gmres_set_extended", None, _vp, C.c_int, C.c_double, C.c_int)
+    sig("orc_gmres_last_stats", None, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp)
     sig("orc_gmres_subspace_vector", _dp, _vp, C.c_int)
     sig("orc_gmres_hessenberg", C.c_double, _vp, C.c_int, C.c_int)
     sig("orc_gmres_hessenberg_data", _dp, _vp)
@@ -251,6 +253,16 @@ class Gmres:
     def set_fixed_preconditioning(self, on):
         lib().orc_gmres_set_fixed_preconditioning(self.h, int(on))
 
+    def set_extended(self, rtol, max_cycles, on=True):
+        """Restarted GMRES(m) with Givens rotations and a residual monitor
+        (the device library's extended mode; not in the reference)."""
+        lib().orc_gmres_set_extended(self.h, int(on), float(rtol), int(max_cycles))
+
+    def last_stats(self):
+        it, cy, cv, rr = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        lib().orc_gmres_last_stats(self.h, C.byref(it), C.byref(cy), C.byref(cv), C.byref(rr))
+        return it.value, cy.value, bool(cv.value), rr.value
+
     def initial_subspace(self, b):
         b, pb = _d(b)
         return lib().orc_gmres_initial_subspace(self.h, pb)
@@ -303,7 +315,7 @@ class ImplicitEuler:
     Functions are evaluated on numpy arrays (or broadcast scalars).
     """
 
-    def __init__(self, corner1, corner2, cx, cy, init, params, bcs, m, tdp=False):
+    def __init__(self, corner1, corner2, cx, cy, init, params, bcs, m, tdp=False, extended=None):
         L = lib()
         self.cx, self.cy, self.m, self.tdp = cx, cy, m, tdp
         self.bcs = {}
@@ -333,6 +345,8 @@ class ImplicitEuler:
         self.n = L.orc_ie_num_eqns(self.h)
         self._push_bc_values(0.0)
         L.orc_ie_init_offdiag(self.h)
+        if extended is not None:
+            self.solver().set_extended(*extended)
 
     # include/mesh.hpp:20-42 (same operation order)
     def left_x(self, i):

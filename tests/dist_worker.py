@@ -7,7 +7,8 @@ MODE numpy : CPU only.  A numpy statement of the row-block algorithm (ghost
              halo rows, all-reduced Gram-Schmidt) on top of the package's
              host collectives; checks the decomposition logic under gloo.
 MODE hip   : the HIP path, every rank on cuda:0, collectives staged through
-             gloo (several ranks may share one GPU this way).
+             gloo (several ranks may share one GPU this way).  A trailing RTOL
+             argument > 0 selects the restarted, residual-monitored solver.
 Rank 0 writes an .npz with the gathered results to OUT.
 """
 import os
@@ -111,7 +112,7 @@ def numpy_mode(out, problem_name, cx, cy, m):
     dist.barrier()
 
 
-def hip_mode(out, problem_name, cx, cy, m, tdp, steps):
+def hip_mode(out, problem_name, cx, cy, m, tdp, steps, rtol=0.0):
     import torch
     import torch.distributed as dist
     from krylov_amd import capi, host, problems
@@ -123,16 +124,19 @@ def hip_mode(out, problem_name, cx, cy, m, tdp, steps):
     hostc = HostCollectives()
     prob = getattr(problems, problem_name)(cx, cy)
     ranges = partition_rows(cx + 2, comm.nranks)
-    dev = host.ImplicitEuler(ctx, **prob, m=m, tdp=bool(tdp), row_range=ranges[comm.rank])
-    deltas = []
+    dev = host.ImplicitEuler(ctx, **prob, m=m, tdp=bool(tdp), row_range=ranges[comm.rank],
+                             extended=(rtol, 60) if rtol > 0.0 else None)
+    deltas, iters = [], []
     for _ in range(steps):
         deltas.append(dev.timestep(0.25))
+        if rtol > 0.0:
+            iters.append(dev.solver().last_stats()[0])
     T = gather_rows(dev.local(capi.LOCAL_T), ranges, hostc)
     U = gather_rows(dev.local(capi.LOCAL_U), ranges, hostc)
     D = gather_rows(dev.local(capi.LOCAL_DELTA), ranges, hostc)
     B = gather_rows(dev.local(capi.LOCAL_RHS), ranges, hostc)
     if comm.rank == 0:
-        np.savez(out, T=T, U=U, D=D, B=B, deltas=np.array(deltas), nranks=comm.nranks,
+        np.savez(out, T=T, U=U, D=D, B=B, deltas=np.array(deltas), iters=np.array(iters), nranks=comm.nranks,
                  allreduces=comm.calls["allreduce"], sendrecvs=comm.calls["sendrecv"])
     dist.barrier()
 
@@ -180,7 +184,7 @@ def main():
             numpy_mode(out, sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
         else:
             hip_mode(out, sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]),
-                     int(sys.argv[8]))
+                     int(sys.argv[8]), float(sys.argv[9]) if len(sys.argv) > 9 else 0.0)
     finally:
         dist.destroy_process_group()
 

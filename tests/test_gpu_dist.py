@@ -42,6 +42,23 @@ def test_slabs_match_single_rank(tmp_path, ctx, oracle, nranks, name, cx, cy, m,
     assert rel(one.compact(r["B"]), one.sol_vec()) <= 1e-8
 
 
+@pytest.mark.parametrize("nranks,name,cx,cy,m,tdp", [(2, "prob1", 38, 18, 10, 0), (3, "prob1", 38, 18, 10, 1)])
+def test_slabs_extended_solver(tmp_path, ctx, oracle, nranks, name, cx, cy, m, tdp):
+    """Restarted solver on row blocks: every rank takes the same stop decision
+    from the all-reduced Hessenberg entries; counts within +-1 of the CPU statement."""
+    steps = 3
+    out = tmp_path / "res.npz"
+    launch(nranks, ["hip", out, name, cx, cy, m, tdp, steps, 1e-12], timeout=600)
+    r = np.load(out)
+    prob = getattr(problems, name)(cx, cy)
+    ref = oracle.ImplicitEuler(**prob, m=m, tdp=bool(tdp), extended=(1e-12, 60))
+    for k in range(steps):
+        d = ref.timestep(0.25)
+        assert abs(int(r["iters"][k]) - ref.solver().last_stats()[0]) <= 1
+        assert abs(float(r["deltas"][k]) - d) <= 1e-10 * abs(d)
+    assert rel(r["T"][1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]) <= 1e-10
+
+
 def test_device_native_callbacks_one_rank(tmp_path):
     """backend nccl with a single rank: the callbacks accept the library's
     device pointers on its stream and leave the data intact."""
