@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--max-cycles", type=int, default=20)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-m", type=int, default=8, help="Arnoldi steps of the CPU sample cycle")
+    ap.add_argument("--cpu-m", type=int, default=12, help="Arnoldi steps of the CPU sample cycle")
     ap.add_argument("--cpu-mesh", type=int, default=0, help="mesh of the CPU sample (0: same as --mesh)")
     return ap.parse_args()
 
