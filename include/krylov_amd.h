@@ -130,6 +130,11 @@ int kry_gmres_initial_subspace(kry_gmres *g, const double *b_host, double *beta)
  * tdiags_host (may be NULL) receives the n x 3 band copy (entries (0,0) and
  * (n-1,2) are NaN as in the reference). */
 int kry_gmres_assemble_preconditioner(kry_gmres *g, kry_op *op, double *tdiags_host);
+/* SparseTriDiagSolver::solve as the preconditioner uses it
+ * (include/solver.hpp:246-273 called from :316-321): out = M^-1 in for the
+ * tridiagonal assembled by kry_gmres_assemble_preconditioner.  Vectors are in
+ * the operator's own layout (padded for a stencil operator), length n. */
+int kry_gmres_apply_preconditioner(kry_gmres *g, const double *in_host, double *out_host);
 /* GMRESSolver::add_arnoldi (include/solver.hpp:185-194) or the TDP override
  * (:316-328), incl. gram_schmidt (:196-211); *h_next = H(j+1, j). */
 int kry_gmres_add_arnoldi(kry_gmres *g, kry_op *op, double *h_next);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "kry_gmres_hessenberg_matrix": (C.c_int, [_vp, _dp]),
     "kry_gmres_prev_result": (C.c_int, [_vp, _dp]),
     "kry_gmres_result_device": (_vp, [_vp]),
+    "kry_gmres_apply_preconditioner": (C.c_int, [_vp, _dp, _dp]),
     "kry_gmres_set_mgs_block": (C.c_int, [_vp, C.c_int]),
     "kry_gmres_get_mgs_block": (C.c_int, [_vp]),
     "kry_gmres_set_tolerance": (C.c_int, [_vp, C.c_double, C.c_int]),

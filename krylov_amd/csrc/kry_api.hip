@@ -888,6 +888,19 @@ int kry_gmres_assemble_preconditioner(kry_gmres *g, kry_op *op, double *tdiags_h
   return KRY_OK;
 }
 
+int kry_gmres_apply_preconditioner(kry_gmres *g, const double *in_host, double *out_host) {
+  if (!g || !in_host || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!(g->flags & KRY_GMRES_TDP)) return fail(KRY_ERR_STATE, "solver was created without KRY_GMRES_TDP");
+  if (!g->tdp_ready) return fail(KRY_ERR_STATE, "preconditioner has not been assembled");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  KCHK(stage_rhs(g, in_host));
+  launch_tdp_apply(g->ctx->stream, g->lo, g->dd, g->ud, g->bbuf, g->z, g->nlines, g->L);
+  KCHK(launch_ok("apply_preconditioner"));
+  HIPCHK(hipMemcpyAsync(out_host, g->z, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  return KRY_OK;
+}
+
 int kry_gmres_add_arnoldi(kry_gmres *g, kry_op *op, double *h_next) {
   KCHK(check_op(g, op));
   HIPCHK(hipSetDevice(g->ctx->device));

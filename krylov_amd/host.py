@@ -138,6 +138,13 @@ class GMRESSolver:
         check(capi.lib().kry_gmres_assemble_preconditioner(self.h, op.h, t.ctypes.data_as(_dp)))
         return t
 
+    def apply_preconditioner(self, v):
+        """M^-1 v for the assembled tridiagonal (operator layout)."""
+        v, pv = _d(v)
+        out = np.empty(self.n)
+        check(capi.lib().kry_gmres_apply_preconditioner(self.h, pv, out.ctypes.data_as(_dp)))
+        return out
+
     def add_arnoldi(self, op):
         h = C.c_double()
         check(capi.lib().kry_gmres_add_arnoldi(self.h, op.h, C.byref(h)))

@@ -459,3 +459,42 @@ def test_full_size_properties(ctx, n, m):
     ls_res = float(np.linalg.norm(e1 - H @ yls))
     assert abs(float(np.linalg.norm(r)) - ls_res) <= 1e-8 * beta
     assert float(np.linalg.norm(r)) < 1e-2 * beta
+
+
+# ---- the line solver on its own ------------------------------------------------------
+
+@pytest.mark.parametrize("cx,cy", [(38, 18), (7, 62), (5, 64), (9, 126), (6, 130), (3, 200), (1030, 70), (2100, 66),
+                                   (4200, 30), (8200, 20), (8200, 70)])
+def test_line_preconditioner_bit_exact(ctx, oracle, cx, cy):
+    """M^-1 v for the tridiagonal of the assembled system against
+    SparseTriDiagSolver::solve (include/solver.hpp:246-273) run as ONE long
+    recurrence over all unknowns, as the reference does: bit-exact.  The shapes
+    cover line lengths below, at and above the 64-column chunk (partial and
+    full chunks, several chunks) and every lines-per-wavefront setting."""
+    prob = problems.s_aniso(cx, cy)
+    ref = oracle.ImplicitEuler(**prob, m=2, tdp=True)
+    dev = host.ImplicitEuler(ctx, **prob, m=2, tdp=True)
+    ref.assemble_system(0.25)
+    dev.assemble_system(0.25)
+    diags = ref.solver().assemble_preconditioner(ref.op())
+    g = dev.solver()
+    g.assemble_preconditioner(dev.operator())
+    rng = np.random.default_rng(cx * 1000 + cy)
+    for scale in (1.0, 1e150):
+        v = rng.uniform(-1.0, 1.0, ref.n) * scale
+        want = oracle.sparse_tridiag_solve(diags, v)
+        got = dev.compact(g.apply_preconditioner(dev.expand(v)))
+        assert np.array_equal(got, want)
+
+
+def test_line_preconditioner_general_matrix_bit_exact(ctx, oracle):
+    """One line of length n (a general matrix has no row structure)."""
+    rng = np.random.default_rng(3)
+    n = 333
+    A = rng.uniform(-1.0, 1.0, (n, n)) + np.diag(rng.uniform(3.0, 5.0, n))
+    g = host.GMRESSolver(ctx, n, 2, tdp=True)
+    g.assemble_preconditioner(host.Operator.dense(ctx, A))
+    ref = oracle.Gmres(n, 2, tdp=True)
+    diags = ref.assemble_preconditioner(oracle.Op.dense(A))
+    v = rng.uniform(-1.0, 1.0, n)
+    assert np.array_equal(g.apply_preconditioner(v), oracle.sparse_tridiag_solve(diags, v))

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <cstring>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -223,6 +224,54 @@ __global__ __launch_bounds__(BLK) void v4(double *w, const double *pbase, const 
   for (int q = 0; q < 10; q++) { double t = block_sum<BLK>(acc[q], s); if (threadIdx.x == 0) part[q * gridDim.x + blockIdx.x] = t; }
 }
 
+// VK: K links per pass (2K+1 reads, 1 write, K dots + K(K-1)/2 Gram entries)
+template <int BLK, int U, int K>
+__global__ __launch_bounds__(BLK) void vk(double *w, const double *pbase, const double *cbase, long ld, double *part, long n2) {
+  __shared__ double s[BLK / 64];
+  constexpr int NQ = K + K * (K - 1) / 2;
+  d2 *w2 = (d2 *)w;
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+  double h[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) h[k] = 1e-3 * (k + 1);
+  const long tile = (long)BLK * U;
+  for (long base = (long)blockIdx.x * tile; base < n2; base += (long)gridDim.x * tile) {
+    d2 wv[U], pv[K][U], cv[K][U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long i = base + u * BLK + threadIdx.x;
+      if (i < n2) {
+        wv[u] = __builtin_nontemporal_load(&w2[i]);
+#pragma unroll
+        for (int k = 0; k < K; k++) pv[k][u] = __builtin_nontemporal_load((const d2 *)(pbase + k * ld) + i);
+#pragma unroll
+        for (int k = 0; k < K; k++) cv[k][u] = __builtin_nontemporal_load((const d2 *)(cbase + k * ld) + i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long i = base + u * BLK + threadIdx.x;
+      if (i < n2) {
+        d2 r = wv[u];
+#pragma unroll
+        for (int k = 0; k < K; k++) r = r - h[k] * pv[k][u];
+        __builtin_nontemporal_store(r, &w2[i]);
+        int q = K;
+#pragma unroll
+        for (int a = 0; a < K; a++) {
+          acc[a] = fma(r.x, cv[a][u].x, acc[a]); acc[a] = fma(r.y, cv[a][u].y, acc[a]);
+#pragma unroll
+          for (int b = a + 1; b < K; b++) { acc[q] = fma(cv[a][u].x, cv[b][u].x, acc[q]); acc[q] = fma(cv[a][u].y, cv[b][u].y, acc[q]); q++; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; q++) { double t = block_sum<BLK>(acc[q], s); if (threadIdx.x == 0) part[q * gridDim.x + blockIdx.x] = t; }
+}
+
 // plain copy for calibration
 template <int BLK, int U, bool NT>
 __global__ __launch_bounds__(BLK) void vcopy(double *w, const double *p, long n2) {
@@ -278,9 +327,18 @@ int main(int argc, char **argv) {
 #define P(r) v[1 + ((r) % 3)]
 #define Cc(r) v[4 + ((r) % 3)]
   char nm[128];
-  // nine vectors with leading dimension ld for the 4+4 sweep
+  // vectors with leading dimension ld for the K+K sweeps
   double *big; const long ld = (n + 31) / 32 * 32;
-  CHECK(hipMalloc((void **)&big, sizeof(double) * ld * 9)); CHECK(hipMemset(big, 0, sizeof(double) * ld * 9));
+  CHECK(hipMalloc((void **)&big, sizeof(double) * ld * 17)); CHECK(hipMemset(big, 0, sizeof(double) * ld * 17));
+  if (argc > 2 && !strcmp(argv[2], "wide")) {
+    // bytes per link: K=4: 20, K=6: 18.7, K=8: 18
+    for (int G : {128, 192, 256, 384, 512}) {
+      snprintf(nm, sizeof nm, "VK 4+4 U1 G%d (80 B)", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((vk<256, 1, 4>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VK 6+6 U1 G%d (112 B)", G); run(nm, 112, [&](int r) { hipLaunchKernelGGL((vk<256, 1, 6>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VK 8+8 U1 G%d (144 B)", G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vk<256, 1, 8>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+    }
+    return 0;
+  }
   run("V1 single link NT U4 G1024 (ref)", 32, [&](int r) { hipLaunchKernelGGL((v1<256, 4, true>), dim3(1024), dim3(256), 0, 0, v[0], P(r), Cc(r), 1e-3, part, n2); });
   for (int G : {256, 384, 512, 640, 768, 1024, 1536, 2048}) {
     snprintf(nm, sizeof nm, "V4 4+4 sweep U1 G%d", G); run(nm, 80, [&](int r) { hipLaunchKernelGGL((v4<256, 1>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 5 * ld, ld, part, n2); });
