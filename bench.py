@@ -78,14 +78,26 @@ def cpu_baseline(mesh, m_sample, dt):
     }
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries underneath (RCCL
+    prints a version banner when its first communicator comes up) write to
+    file descriptor 1 as they please, so descriptor 1 is pointed at stderr for
+    the rest of the run and the JSON line goes to the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    out_stream = claim_stdout()
     if world > 1:
         from krylov_amd import dist_bench
-        return dist_bench.run(args, world, rank, local_rank)
+        return dist_bench.run(args, world, rank, local_rank, out_stream)
 
     import torch
     from krylov_amd import capi, host, problems
@@ -185,7 +197,7 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n_side, args.cpu_m, dt)
-    print(json.dumps(out))
+    print(json.dumps(out), file=out_stream, flush=True)
 
 
 if __name__ == "__main__":

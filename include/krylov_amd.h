@@ -88,6 +88,20 @@ typedef int (*kry_sendrecv_fn)(void *user, const double *send_dev, int send_peer
                                int recv_peer, int64_t count, void *stream);
 int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allreduce,
                      kry_sendrecv_fn sendrecv, void *user);
+/* Alternative to the callbacks: the library issues the collectives itself
+ * through RCCL on the context's stream (ncclAllReduce; the four halo transfers
+ * of an exchange as one ncclGroup), which also lets a captured step (hipGraph)
+ * contain them.  One rank obtains a 128-byte id with kry_rccl_unique_id and
+ * hands it to all ranks by whatever launcher is in use (MPI, torch.distributed
+ * store, a file); every rank then calls kry_ctx_set_comm_rccl (collective:
+ * returns when all nranks have joined).  librccl is loaded on first use; a copy
+ * already present in the process is reused.  No counterpart in the reference. */
+int kry_rccl_unique_id(unsigned char id[128]);
+int kry_ctx_set_comm_rccl(kry_ctx *ctx, int rank, int nranks, const unsigned char id[128]);
+int kry_ctx_comm_is_native(const kry_ctx *ctx);
+/* Collective check of whatever communication is installed: sum and max
+ * all-reduce of the rank numbers and a ring exchange, verified on every rank. */
+int kry_ctx_comm_selftest(kry_ctx *ctx);
 int kry_ctx_rank(const kry_ctx *ctx);
 int kry_ctx_nranks(const kry_ctx *ctx);
 /* Optional instrumentation (off by default): bracket every kernel launch with

@@ -41,7 +41,7 @@ def build_lib(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, "kry_internal.h"), os.path.join(ROOT, "include", "krylov_amd.h")]
     if not force and _newer(LIB, deps):
         return LIB
-    cmd = [hipcc()] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB]
+    cmd = [hipcc()] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -8,9 +8,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded on demand
 
 #include "kry_internal.h"
 
@@ -69,7 +74,59 @@ struct kry_ctx {
   kry_allreduce_fn allreduce = nullptr;
   kry_sendrecv_fn sendrecv = nullptr;
   void *comm_user = nullptr;
+  // ... or the library talks to RCCL itself on `stream` (kry_ctx_set_comm_rccl)
+  ncclComm_t nccl = nullptr;
 };
+
+// RCCL entry points, resolved at run time so that single-GPU users never load
+// the (large) collective library.  A copy that is already in the process - the
+// one PyTorch links - is reused.
+struct RcclApi {
+  void *handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+
+static const RcclApi &rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *nm : names)
+      if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *nm : names)
+      if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (!api.handle) return;
+#define KRY_RCCL_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, #sym))
+    KRY_RCCL_SYM(GetUniqueId, ncclGetUniqueId);
+    KRY_RCCL_SYM(CommInitRank, ncclCommInitRank);
+    KRY_RCCL_SYM(CommDestroy, ncclCommDestroy);
+    KRY_RCCL_SYM(AllReduce, ncclAllReduce);
+    KRY_RCCL_SYM(Send, ncclSend);
+    KRY_RCCL_SYM(Recv, ncclRecv);
+    KRY_RCCL_SYM(GroupStart, ncclGroupStart);
+    KRY_RCCL_SYM(GroupEnd, ncclGroupEnd);
+    KRY_RCCL_SYM(GetErrorString, ncclGetErrorString);
+#undef KRY_RCCL_SYM
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Send && api.Recv &&
+             api.GroupStart && api.GroupEnd && api.GetErrorString;
+  });
+  return api;
+}
+
+#define NCCLCHK(call)                                                                     \
+  do {                                                                                    \
+    ncclResult_t r_ = (call);                                                             \
+    if (r_ != ncclSuccess) return fail(KRY_ERR_HIP, "%s: %s", #call, rccl_api().GetErrorString(r_)); \
+  } while (0)
 
 // Brackets the launches issued in its scope with two events on the context's
 // stream when timing is enabled; a no-op otherwise.
@@ -244,6 +301,7 @@ static void ctx_free(kry_ctx *ctx) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->nccl) (void)rccl_api().CommDestroy(ctx->nccl);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -261,6 +319,7 @@ int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allred
   if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(KRY_ERR_INVALID, "bad rank %d of %d", rank, nranks);
   if (nranks > 1 && (!allreduce || !sendrecv)) return fail(KRY_ERR_INVALID, "collectives are required for nranks > 1");
+  if (ctx->nccl) return fail(KRY_ERR_STATE, "the context already communicates through RCCL");
   ctx->rank = rank;
   ctx->nranks = nranks;
   ctx->allreduce = allreduce;
@@ -268,6 +327,39 @@ int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allred
   ctx->comm_user = user;
   return KRY_OK;
 }
+
+int kry_rccl_unique_id(unsigned char id[128]) {
+  if (!id) return fail(KRY_ERR_INVALID, "id is NULL");
+  const RcclApi &api = rccl_api();
+  if (!api.ok) return fail(KRY_ERR_STATE, "librccl could not be loaded: %s", dlerror());
+  static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
+  ncclUniqueId u;
+  NCCLCHK(api.GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return KRY_OK;
+}
+
+int kry_ctx_set_comm_rccl(kry_ctx *ctx, int rank, int nranks, const unsigned char id[128]) {
+  if (!ctx || !id) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(KRY_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+  if (ctx->nccl) return fail(KRY_ERR_STATE, "the context already communicates through RCCL");
+  const RcclApi &api = rccl_api();
+  if (!api.ok) return fail(KRY_ERR_STATE, "librccl could not be loaded: %s", dlerror());
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(api.CommInitRank(&comm, nranks, u, rank));
+  ctx->nccl = comm;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  ctx->allreduce = nullptr;
+  ctx->sendrecv = nullptr;
+  ctx->comm_user = nullptr;
+  return KRY_OK;
+}
+
+int kry_ctx_comm_is_native(const kry_ctx *ctx) { return ctx && ctx->nccl ? 1 : 0; }
 
 int kry_ctx_rank(const kry_ctx *ctx) { return ctx ? ctx->rank : 0; }
 int kry_ctx_nranks(const kry_ctx *ctx) { return ctx ? ctx->nranks : 1; }
@@ -309,6 +401,12 @@ static int dev_alloc(double **p, int64_t count) {
 
 // In-place reduction of `count` doubles on the device over all ranks.
 static int comm_allreduce(kry_ctx *ctx, double *buf, int64_t count, int op) {
+  if (ctx->nccl) {  // also with one rank: the caller asked for RCCL
+    if (ctx->nranks == 1) return KRY_OK;
+    NCCLCHK(rccl_api().AllReduce(buf, buf, (size_t)count, ncclDouble, op == KRY_REDUCE_MAX ? ncclMax : ncclSum,
+                                 ctx->nccl, ctx->stream));
+    return KRY_OK;
+  }
   if (ctx->nranks == 1) return KRY_OK;
   const int rc = ctx->allreduce(ctx->comm_user, buf, count, op, (void *)ctx->stream);
   if (rc != 0) return fail(KRY_ERR_STATE, "allreduce callback failed with %d", rc);
@@ -318,13 +416,85 @@ static int comm_allreduce(kry_ctx *ctx, double *buf, int64_t count, int op) {
 // Fill the halo rows of a slab vector: `local` addresses the first owned row,
 // rows hold P entries, nloc entries are owned.  The lower neighbour (rank-1)
 // receives my first row as its upper halo, the upper neighbour my last row.
+// Through RCCL all four transfers form one group (one launch on the stream).
 static int comm_halo(kry_ctx *ctx, double *local, int64_t P, int64_t nloc) {
   if (ctx->nranks == 1) return KRY_OK;
   const int down = ctx->rank > 0 ? ctx->rank - 1 : -1;
   const int up = ctx->rank + 1 < ctx->nranks ? ctx->rank + 1 : -1;
+  if (ctx->nccl) {
+    const RcclApi &api = rccl_api();
+    NCCLCHK(api.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (down >= 0) {
+      if (r == ncclSuccess) r = api.Send(local, (size_t)P, ncclDouble, down, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.Recv(local - P, (size_t)P, ncclDouble, down, ctx->nccl, ctx->stream);
+    }
+    if (up >= 0) {
+      if (r == ncclSuccess) r = api.Send(local + nloc - P, (size_t)P, ncclDouble, up, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.Recv(local + nloc, (size_t)P, ncclDouble, up, ctx->nccl, ctx->stream);
+    }
+    const ncclResult_t e = api.GroupEnd();
+    if (r != ncclSuccess) return fail(KRY_ERR_HIP, "ncclSend/ncclRecv: %s", api.GetErrorString(r));
+    if (e != ncclSuccess) return fail(KRY_ERR_HIP, "ncclGroupEnd: %s", api.GetErrorString(e));
+    return KRY_OK;
+  }
   int rc = ctx->sendrecv(ctx->comm_user, local, down, local + nloc, up, P, (void *)ctx->stream);
   if (rc == 0) rc = ctx->sendrecv(ctx->comm_user, local + nloc - P, up, local - P, down, P, (void *)ctx->stream);
   if (rc != 0) return fail(KRY_ERR_STATE, "sendrecv callback failed with %d", rc);
+  return KRY_OK;
+}
+
+// One send and one receive of `count` doubles (a peer < 0: no such transfer).
+static int comm_sendrecv(kry_ctx *ctx, const double *send, int send_peer, double *recv, int recv_peer, int64_t count) {
+  if (ctx->nccl) {
+    const RcclApi &api = rccl_api();
+    NCCLCHK(api.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (send_peer >= 0) r = api.Send(send, (size_t)count, ncclDouble, send_peer, ctx->nccl, ctx->stream);
+    if (recv_peer >= 0 && r == ncclSuccess) r = api.Recv(recv, (size_t)count, ncclDouble, recv_peer, ctx->nccl, ctx->stream);
+    const ncclResult_t e = api.GroupEnd();
+    if (r != ncclSuccess) return fail(KRY_ERR_HIP, "ncclSend/ncclRecv: %s", api.GetErrorString(r));
+    if (e != ncclSuccess) return fail(KRY_ERR_HIP, "ncclGroupEnd: %s", api.GetErrorString(e));
+    return KRY_OK;
+  }
+  if (!ctx->sendrecv) return fail(KRY_ERR_STATE, "no collectives installed");
+  const int rc = ctx->sendrecv(ctx->comm_user, send, send_peer, recv, recv_peer, count, (void *)ctx->stream);
+  if (rc != 0) return fail(KRY_ERR_STATE, "sendrecv callback failed with %d", rc);
+  return KRY_OK;
+}
+
+extern "C" int kry_ctx_comm_selftest(kry_ctx *ctx) {
+  if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
+  if (!ctx->nccl && ctx->nranks > 1 && (!ctx->allreduce || !ctx->sendrecv))
+    return fail(KRY_ERR_STATE, "no collectives installed");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = ctx->nranks, me = ctx->rank;
+  double *buf = nullptr;
+  HIPCHK(hipMalloc((void **)&buf, 4 * sizeof(double)));
+  double h[4] = {me + 1.0, me + 1.0, 100.0 + me, -1.0};
+  int st = KRY_OK;
+  if (hipMemcpyAsync(buf, h, sizeof h, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = fail(KRY_ERR_HIP, "copy failed");
+  if (st == KRY_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(KRY_ERR_HIP, "sync failed");
+  if (st == KRY_OK) {
+    if (ctx->nccl) {  // drive RCCL even in a group of one
+      const RcclApi &api = rccl_api();
+      ncclResult_t r = api.AllReduce(buf, buf, 1, ncclDouble, ncclSum, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.AllReduce(buf + 1, buf + 1, 1, ncclDouble, ncclMax, ctx->nccl, ctx->stream);
+      if (r != ncclSuccess) st = fail(KRY_ERR_HIP, "ncclAllReduce: %s", api.GetErrorString(r));
+    } else if (n > 1) {
+      st = comm_allreduce(ctx, buf, 1, KRY_REDUCE_SUM);
+      if (st == KRY_OK) st = comm_allreduce(ctx, buf + 1, 1, KRY_REDUCE_MAX);
+    }
+  }
+  if (st == KRY_OK && (ctx->nccl || n > 1)) st = comm_sendrecv(ctx, buf + 2, (me + 1) % n, buf + 3, (me + n - 1) % n, 1);
+  if (st == KRY_OK && hipMemcpyAsync(h, buf, sizeof h, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = fail(KRY_ERR_HIP, "copy failed");
+  if (st == KRY_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(KRY_ERR_HIP, "sync failed");
+  (void)hipFree(buf);
+  if (st != KRY_OK) return st;
+  const double want_sum = 0.5 * n * (n + 1.0), want_max = (double)n, want_tok = 100.0 + (me + n - 1) % n;
+  if (h[0] != want_sum || h[1] != want_max || ((ctx->nccl || n > 1) && h[3] != want_tok))
+    return fail(KRY_ERR_STATE, "collectives returned sum %g (want %g), max %g (want %g), ring token %g (want %g)", h[0],
+                want_sum, h[1], want_max, h[3], want_tok);
   return KRY_OK;
 }
 
@@ -1209,7 +1379,7 @@ static int ie_step_async(kry_ie *ie, double dt) {
   if (!ie->solver) return fail(KRY_ERR_STATE, "step object was created without a solver");
   hipStream_t st = ie->ctx->stream;
   // the restarted solver reads its state on the host between cycles: no capture
-  if (!ie->use_graph || ie->ctx->nranks > 1 || (ie->solver->flags & KRY_GMRES_EXTENDED)) {
+  if (!ie->use_graph || (ie->ctx->nranks > 1 && !ie->ctx->nccl) || (ie->solver->flags & KRY_GMRES_EXTENDED)) {
     KCHK(ie_step_body(ie, dt, false));
   } else {
     if (!ie->graph_exec || ie->graph_dt != dt) {

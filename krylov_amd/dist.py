@@ -4,8 +4,10 @@ The C library owns the distributed algorithm (which rows travel where, which
 scalars are summed when); this module supplies the two collectives it calls
 back for, on top of ``torch.distributed``:
 
-  * backend ``nccl`` (RCCL over xGMI): device tensors wrapping the library's
-    buffers, enqueued on the context's stream;
+  * ``RcclComm``: the library calls RCCL itself on its stream; Python only
+    hands the communicator id around (the fast path on real multi-GPU nodes);
+  * ``TorchComm`` with backend ``nccl`` (RCCL over xGMI): device tensors
+    wrapping the library's buffers, enqueued on the context's stream;
   * any other backend (``gloo``): the buffers are staged through host memory.
     Slower, but it lets several ranks share one GPU, or none at all (tests).
 
@@ -162,6 +164,32 @@ class TorchComm:
         except Exception as e:
             print("krylov_amd.dist: sendrecv failed: %r" % (e,), flush=True)
             return 1
+
+
+class RcclComm:
+    """The library issues its collectives through RCCL itself (no Python in the
+    data path, hipGraph-capturable); torch.distributed only carries the
+    128-byte communicator id from rank 0 to the other ranks."""
+
+    device_native = True
+
+    def __init__(self, ctx, group=None):
+        import torch.distributed as dist
+        self.ctx = ctx
+        self.rank = dist.get_rank(group)
+        self.nranks = dist.get_world_size(group)
+        L = capi.lib()
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            capi.check(L.kry_rccl_unique_id(buf))
+        box = [bytes(buf.raw) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        capi.check(L.kry_ctx_set_comm_rccl(ctx.h, self.rank, self.nranks, box[0]))
+        self.calls = {"allreduce": None, "sendrecv": None}  # not counted: nothing passes through Python
+        ctx._comm = self
+
+    def selftest(self):
+        capi.check(capi.lib().kry_ctx_comm_selftest(self.ctx.h))
 
 
 def gather_rows(local, ranges, host):

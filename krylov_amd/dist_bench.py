@@ -3,14 +3,15 @@ blocks, one rank per GPU (strong scaling), halo rows and dot products over
 RCCL (torch.distributed backend "nccl")."""
 import json
 import os
+import sys
 import time
 
 
-def run(args, world, rank, local_rank):
+def run(args, world, rank, local_rank, out_stream=None):
     import torch
     import torch.distributed as dist
     from krylov_amd import capi, host, problems
-    from krylov_amd.dist import TorchComm, partition_rows
+    from krylov_amd.dist import RcclComm, TorchComm, partition_rows
 
     backend = os.environ.get("KRY_DIST_BACKEND", "nccl")
     device = local_rank
@@ -19,17 +20,55 @@ def run(args, world, rank, local_rank):
         device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
     dist.init_process_group(backend)
-    ctx = host.Context(device)
-    comm = TorchComm(ctx)
+
+    # Collectives: the library's own RCCL calls when every rank has its own GPU, the
+    # torch.distributed callbacks otherwise (KRY_DIST_COMM=torch|rccl overrides).  Either
+    # choice is first validated on a small mesh against a single-rank replica run by every
+    # rank; if the library-side RCCL path fails that check the callbacks take over.
+    def make(kind):
+        c = host.Context(device)
+        return c, (RcclComm(c) if kind == "rccl" else TorchComm(c))
+
+    def selfcheck(c):
+        capi.check(capi.lib().kry_ctx_comm_selftest(c.h))
+        prob, mm = problems.s_iso(96, 64), 8
+        part = host.ImplicitEuler(c, **prob, m=mm, row_range=partition_rows(98, world)[rank])
+        one = host.ImplicitEuler(host.Context(device), **prob, m=mm)
+        err = 0.0
+        for _ in range(2):
+            a, b = part.timestep(0.25), one.timestep(0.25)
+            err = max(err, abs(a - b) / abs(b))
+        return err
+
+    want = os.environ.get("KRY_DIST_COMM", "rccl" if backend == "nccl" else "torch")
+    comm_kind, check_err, ctx, comm = None, None, None, None
+    for kind in ([want] if want == "torch" else [want, "torch"]):
+        try:
+            ctx, comm = make(kind)
+            check_err = selfcheck(ctx)
+            ok = check_err <= 1e-9
+        except Exception as e:  # noqa: BLE001 - any failure means: try the other transport
+            if rank == 0:
+                print("krylov_amd.dist_bench: %s collectives unusable: %r" % (kind, e), file=sys.stderr, flush=True)
+            ok = False
+        flag = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            comm_kind = kind
+            break
+    if comm_kind is None:
+        raise RuntimeError("no working collectives (self-check error %r)" % (check_err,))
     n_side, m, dt = args.mesh, args.m, args.dt
     ranges = partition_rows(n_side + 2, world)
     dev = host.ImplicitEuler(ctx, **problems.s_iso(n_side), m=m, bc_time_dependent=False,
-                             row_range=ranges[rank])
+                             row_range=ranges[rank], use_graph=args.graph)
     N = dev.n
     nloc = dev.nloc
     for _ in range(args.warmup):
         dev.timestep(dt)
-    timing = not args.no_kernel_timing
+    if comm_kind == "torch":
+        comm.calls = {"allreduce": 0, "sendrecv": 0}  # count the timed steps only
+    timing = not (args.no_kernel_timing or args.graph)
     ctx.set_kernel_timing(timing)
     ctx.kernel_times()
     ctx.synchronize()
@@ -88,10 +127,11 @@ def run(args, world, rank, local_rank):
             "last_max_delta": last,
             "rank0_kernel_ms_per_step": round(kernel_ms / args.steps, 2),
             "rank0_comm_and_gap_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms / args.steps, 2),
-            "collectives_per_step": {k: v // (args.steps + args.warmup + 1) for k, v in comm.calls.items()},
+            "collectives": comm_kind, "collectives_selfcheck_rel_err": check_err,
+            "collectives_per_step": {k: (v // args.steps if v is not None else None) for k, v in comm.calls.items()},
             "kernels": kernels,
             "roofline": roofline,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=out_stream or sys.stdout, flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -162,24 +162,68 @@ def nccl_selftest(out):
     rc = comm._allreduce(None, ptr, dev.nloc, capi.REDUCE_SUM, None)
     rc2 = comm._allreduce(None, ptr, 1, capi.REDUCE_MAX, None)
     rc3 = comm._sendrecv(None, ptr, -1, ptr, -1, 20, None)
+    # a grouped send + receive through RCCL with this rank as its own peer, on raw
+    # device pointers as the library hands them over
+    scratch = torch.arange(64, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    sp = scratch.data_ptr()
+    rc4 = comm._sendrecv(None, sp, 0, sp + 40 * 8, 0, 20, None)
     ctx.synchronize()
+    got = scratch.cpu().numpy()
+    p2p_ok = bool(np.array_equal(got[40:60], np.arange(20.0)) and np.array_equal(got[:40], np.arange(40.0)))
+    # time the grouped exchange as the halo exchange issues it
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        comm._sendrecv(None, sp, 0, sp + 40 * 8, 0, 20, None)
+    ctx.synchronize()
+    us_p2p = (time.perf_counter() - t0) / 100 * 1e6
     t0 = time.perf_counter()
     for _ in range(200):
         comm._allreduce(None, ptr, 10, capi.REDUCE_SUM, None)
     ctx.synchronize()
     us = (time.perf_counter() - t0) / 200 * 1e6
     after = dev.sol_vec()
-    np.savez(out, rc=rc, rc2=rc2, rc3=rc3, same=bool(np.array_equal(before, after)), us_per_allreduce=us)
+    np.savez(out, rc=rc, rc2=rc2, rc3=rc3, rc4=rc4, p2p_ok=p2p_ok, same=bool(np.array_equal(before, after)),
+             us_per_allreduce=us, us_per_sendrecv=us_p2p)
+    dist.barrier()
+
+
+def rccl_selftest(out):
+    """One rank, the library's own RCCL calls: communicator set-up from a
+    broadcast id, the collective self-test (all-reduce and a send/receive with
+    this rank as its own peer, through RCCL even in a group of one), and a
+    slab run - eager and replayed from a hipGraph - against the plain one."""
+    import torch
+    import torch.distributed as dist
+    from krylov_amd import capi, host, problems
+    from krylov_amd.dist import RcclComm
+
+    torch.cuda.set_device(0)
+    ctx = host.Context(0)
+    comm = RcclComm(ctx)
+    comm.selftest()
+    native = capi.lib().kry_ctx_comm_is_native(ctx.h)
+    prob = problems.prob1()
+    plain = host.ImplicitEuler(host.Context(0), **prob, m=10)
+    slab = host.ImplicitEuler(ctx, **prob, m=10, row_range=(0, 40))
+    graph = host.ImplicitEuler(ctx, **prob, m=10, row_range=(0, 40), use_graph=True)
+    d = [[s.timestep(0.25) for _ in range(5)] for s in (plain, slab, graph)]
+    np.savez(out, native=native, plain=np.array(d[0]), slab=np.array(d[1]), graph=np.array(d[2]),
+             same_T=bool(np.array_equal(plain.field(0), slab.field(0), equal_nan=True)
+                         and np.array_equal(plain.field(0), graph.field(0), equal_nan=True)))
     dist.barrier()
 
 
 def main():
     import torch.distributed as dist
     mode, out = sys.argv[1], sys.argv[2]
-    dist.init_process_group("nccl" if mode == "nccl_selftest" else "gloo")
+    dist.init_process_group("nccl" if mode in ("nccl_selftest", "rccl_selftest") else "gloo")
     try:
         if mode == "nccl_selftest":
             nccl_selftest(out)
+        elif mode == "rccl_selftest":
+            rccl_selftest(out)
         elif mode == "numpy":
             numpy_mode(out, sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
         else:

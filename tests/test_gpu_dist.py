@@ -65,6 +65,45 @@ def test_device_native_callbacks_one_rank(tmp_path):
     out = tmp_path / "nccl.npz"
     launch(1, ["nccl_selftest", out], timeout=600)
     r = np.load(out)
-    assert int(r["rc"]) == 0 and int(r["rc2"]) == 0 and int(r["rc3"]) == 0
-    assert bool(r["same"])
-    print("python-driven all-reduce of 10 doubles: %.1f us per call" % float(r["us_per_allreduce"]))
+    assert int(r["rc"]) == 0 and int(r["rc2"]) == 0 and int(r["rc3"]) == 0 and int(r["rc4"]) == 0
+    assert bool(r["same"]) and bool(r["p2p_ok"])
+    print("python-driven all-reduce of 10 doubles: %.1f us per call; grouped send+recv of 20 doubles: %.1f us"
+          % (float(r["us_per_allreduce"]), float(r["us_per_sendrecv"])))
+
+
+def test_library_side_rccl_one_rank(tmp_path):
+    """kry_ctx_set_comm_rccl in a group of one: id hand-over, communicator,
+    ncclAllReduce and grouped ncclSend/ncclRecv on the library's stream
+    (kry_ctx_comm_selftest), and a slab run that must equal the plain run."""
+    out = tmp_path / "rccl.npz"
+    launch(1, ["rccl_selftest", out], timeout=600)
+    r = np.load(out)
+    assert int(r["native"]) == 1
+    assert np.array_equal(r["plain"], r["slab"]) and np.array_equal(r["plain"], r["graph"])
+    assert bool(r["same_T"])
+
+
+def test_bench_contract_two_ranks_shared_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one
+    process per rank), rehearsed with both ranks on this GPU and host-staged
+    collectives: one JSON line from rank 0 with the contract's fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KRY_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--mesh", "256", "--gmres-m", "10"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, p.stdout[-2000:]  # nothing but the JSON line on stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64"
+    assert d["collectives"] == "torch" and d["collectives_selfcheck_rel_err"] <= 1e-9
+    assert abs(d["value"] - 10 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
