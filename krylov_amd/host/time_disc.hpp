@@ -80,15 +80,15 @@ protected:
   }
 
   // Samples the twelve boundary functions at the reference's coordinates
-  // (include/time_disc.hpp:55-76) for the current time.
-  void push_bc_values() {
+  // (include/time_disc.hpp:55-76) for time t; out[f * 4 + side] holds one
+  // value per boundary cell of that side.
+  void sample_bc_values(const real t, std::vector<real> (&out)[12]) const {
     const int cx = cur_state.cells_x(), cy = cur_state.cells_y();
-    const real t = cur_time();
-    std::vector<real> vals;
     for (int f = 0; f < 3; f++)
       for (int side = 0; side < 4; side++) {
         const auto &fn = bcs_[f * 4 + side].second;
         const bool horiz = side == KRY_SIDE_BOTTOM || side == KRY_SIDE_TOP;
+        std::vector<real> &vals = out[f * 4 + side];
         vals.resize(horiz ? cx : cy);
         for (int k = 0; k < (int)vals.size(); k++) {
           real x, y;
@@ -98,8 +98,27 @@ protected:
           else { x = cur_state.right_x(cx - 1); y = cur_state.median_y(k); }
           vals[k] = fn(x, y, t);
         }
-        krylov::check(kry_ie_set_bc_values(ie_, f, side, vals.data(), (int)vals.size()), "kry_ie_set_bc_values");
       }
+  }
+
+  // Hands sampled values to the device object (waits for queued device work
+  // that may still read the previous values).
+  void stage_bc_values(const std::vector<real> (&vals)[12], const real t) {
+    for (int f = 0; f < 3; f++)
+      for (int side = 0; side < 4; side++)
+        krylov::check(kry_ie_set_bc_values(ie_, f, side, vals[f * 4 + side].data(), (int)vals[f * 4 + side].size()),
+                      "kry_ie_set_bc_values");
+    staged_ = true;
+    staged_time_ = t;
+  }
+
+  // Boundary values of the current time on the device, sampling only if the
+  // staged ones belong to another time.
+  void push_bc_values() {
+    const real t = cur_time();
+    if (staged_ && staged_time_ == t) return;
+    sample_bc_values(t, bc_scratch_);
+    stage_bc_values(bc_scratch_, t);
   }
 
   void apply_bcs() {
@@ -112,6 +131,9 @@ protected:
   std::pair<real, real> corner_1_, corner_2_;
   BCSpec bcs_[12];
   kry_ie *ie_ = nullptr;
+  std::vector<real> bc_scratch_[12];
+  bool staged_ = false;
+  real staged_time_ = 0.0;
 };
 
 template <typename SpaceDisc_, typename Solver_> class ImplicitEuler : public TimeDisc<SpaceDisc_> {
@@ -132,10 +154,18 @@ public:
     krylov::check(kry_ie_init_offdiag(this->ie_), "kry_ie_init_offdiag");
   }
 
+  // The step is queued on the device and, while it runs, the boundary
+  // functions are sampled for the time the NEXT step will start from (they
+  // depend on position and time only); for Python callables that is the
+  // expensive host part of a step, and it is hidden behind the device work.
   real timestep(const real dt) {
     this->push_bc_values();
+    krylov::check(kry_ie_timestep_async(this->ie_, dt), "kry_ie_timestep_async");
+    const real t_next = this->cur_time();
+    this->sample_bc_values(t_next, this->bc_scratch_);
     real max_delta = 0.0;
-    krylov::check(kry_ie_timestep(this->ie_, dt, &max_delta), "kry_ie_timestep");
+    krylov::check(kry_ie_last_max_delta(this->ie_, &max_delta), "kry_ie_last_max_delta");
+    this->stage_bc_values(this->bc_scratch_, t_next);
     return max_delta;
   }
 
