@@ -250,6 +250,18 @@ int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta);
  * steps with time-independent boundary values); fetch with kry_ie_last_max_delta. */
 int kry_ie_timestep_async(kry_ie *ie, double dt);
 int kry_ie_last_max_delta(kry_ie *ie, double *max_delta);
+/* ImplicitEulerApproxFact::timestep (include/time_disc.hpp:443-485): ghost
+ * fill, one tridiagonal solve per mesh column along y with right-hand side
+ * dt (flux_integral + source_fd), one per mesh row along x, T += dT; returns
+ * the reference's maximum (taken over solution entries 0..cx-1 of every x
+ * line, :479).  The step object must have been created with m = 0 (it uses
+ * the operator storage for the line systems) and own the whole mesh. */
+int kry_ie_timestep_approx_fact(kry_ie *ie, double dt, double *max_delta);
+/* assemble_system_dy(dt, i) (along_y != 0, include/time_disc.hpp:487-507) or
+ * assemble_system_dx(dt, j) (:509-529) for the current ghost values: rows x 3
+ * row-major (lower, diagonal, upper), rows = cy + 2 or cx + 2; the two
+ * entries the reference never uses are signalling NaN as there. */
+int kry_ie_get_af_system(kry_ie *ie, int along_y, int index, double dt, double *out);
 /* Replay the step through a captured hipGraph (1) or launch kernels eagerly (0). */
 int kry_ie_use_graph(kry_ie *ie, int on);
 /* TimeDisc::cur_time, include/time_disc.hpp:138 */

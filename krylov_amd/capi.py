@@ -81,6 +81,8 @@ SIGNATURES = {
     "kry_ie_timestep": (C.c_int, [_vp, C.c_double, _dp]),
     "kry_ie_timestep_async": (C.c_int, [_vp, C.c_double]),
     "kry_ie_last_max_delta": (C.c_int, [_vp, _dp]),
+    "kry_ie_timestep_approx_fact": (C.c_int, [_vp, C.c_double, _dp]),
+    "kry_ie_get_af_system": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _dp]),
     "kry_ie_use_graph": (C.c_int, [_vp, C.c_int]),
     "kry_ie_time": (C.c_double, [_vp]),
     "kry_ie_num_eqns": (C.c_int64, [_vp]),

@@ -1481,6 +1481,71 @@ int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta) {
   return KRY_OK;
 }
 
+// ImplicitEulerApproxFact::timestep, include/time_disc.hpp:443-485.  The five
+// band arrays and the right-hand-side array of the step object serve as the
+// line systems' storage (lo, di, up, pivots, normalised upper diagonal,
+// right-hand side / solution), which is why the object must not own a solver.
+int kry_ie_timestep_approx_fact(kry_ie *ie, double dt, double *max_delta) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (ie->solver) return fail(KRY_ERR_STATE, "approximate factorisation needs a step object created with m = 0");
+  if (!ie->whole() || ie->ctx->nranks > 1)
+    return fail(KRY_ERR_STATE, "approximate factorisation is not available on row blocks (the x sweeps cross ranks)");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  hipStream_t st = ie->ctx->stream;
+  ScopedKernelTimer t(ie->ctx, KRY_K_ASSEMBLY);
+  KCHK(ie_apply_bcs_async(ie, false));
+  double *lo = ie->band[0], *di = ie->band[1], *up = ie->band[2], *dd = ie->band[3], *ud = ie->band[4];
+  launch_af_rows_y(st, ie->g, ie->bc, dt, ie->fld[0], ie->fld[1], ie->fld[2], lo, di, up, ie->rhs);
+  const int64_t lines = ie->g.rows, L = ie->g.cy + 2;
+  launch_tdp_factor(st, lo, di, up, dd, ud, lines, L);
+  launch_tdp_apply(st, lo, dd, ud, ie->rhs, ie->rhs, lines, L);
+  int np = 0;
+  launch_af_sweep_x(st, ie->g, ie->bc, dt, ie->fld[0], ie->fld[1], ie->rhs, dd, ud, ie->parts, &np);
+  launch_max_final(st, ie->parts, np, ie->maxd);
+  KCHK(launch_ok("approximate factorisation step"));
+  HIPCHK(hipMemcpyAsync(ie->maxd_h, ie->maxd, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  ie->pending = false;
+  ie->time += dt;
+  if (max_delta) *max_delta = *ie->maxd_h;
+  return KRY_OK;
+}
+
+// assemble_system_dx / assemble_system_dy, include/time_disc.hpp:487-529, for
+// inspection: the three coefficients of every row of one line, computed on the
+// host from the device's current velocity field with the expressions of the
+// device kernels.
+int kry_ie_get_af_system(kry_ie *ie, int along_y, int index, double dt, double *out) {
+  if (!ie || !out) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!ie->whole()) return fail(KRY_ERR_STATE, "not available on row blocks");
+  const int cx = ie->g.cx, cy = ie->g.cy, P = cy + 2;
+  if (index < 0 || index >= (along_y ? cx : cy)) return fail(KRY_ERR_INVALID, "line index %d out of range", index);
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_wait(ie));
+  std::vector<double> vel((size_t)(cx + 2) * P);
+  HIPCHK(hipMemcpy(vel.data(), ie->fld[along_y ? 2 : 1], sizeof(double) * vel.size(), hipMemcpyDeviceToHost));
+  const IeGeom &g = ie->g;
+  const int rows = (along_y ? cy : cx) + 2;
+  const double *w = ie->bc.weight;
+  out[0] = kSNaN;
+  out[1] = 1.0;
+  out[2] = 2.0 * w[along_y ? KRY_SIDE_BOTTOM : KRY_SIDE_LEFT] - 1.0;
+  out[(size_t)(rows - 1) * 3 + 0] = 2.0 * w[along_y ? KRY_SIDE_TOP : KRY_SIDE_RIGHT] - 1.0;
+  out[(size_t)(rows - 1) * 3 + 1] = 1.0;
+  out[(size_t)(rows - 1) * 3 + 2] = kSNaN;
+  for (int r = 1; r < rows - 1; r++) {
+    // padded position of the cell and of its two neighbours along the line
+    const size_t k = along_y ? (size_t)(index + 1) * P + r : (size_t)r * P + (index + 1);
+    const size_t step = along_y ? 1 : (size_t)P;
+    const double h = along_y ? g.dy : g.dx;
+    const double kh = g.diffusion * g.inv_rp / h;
+    out[(size_t)r * 3 + 0] = (-vel[k - step] / 2.0 - kh) / h * dt;
+    out[(size_t)r * 3 + 1] = 2.0 * g.diffusion * g.inv_rp / (h * h) * dt + 1.0;
+    out[(size_t)r * 3 + 2] = (vel[k + step] / 2.0 - kh) / h * dt;
+  }
+  return KRY_OK;
+}
+
 int kry_ie_use_graph(kry_ie *ie, int on) {
   if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
   ie->use_graph = on != 0;

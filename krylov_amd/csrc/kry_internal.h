@@ -133,6 +133,12 @@ void launch_assemble(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt,
 void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double *delta,
                        double *part, int *nparts);
 void launch_max_final(hipStream_t st, const double *part, int nparts, double *out);
+// Approximate factorisation: y-direction line systems (coefficients and right-hand
+// side, padded layout), and the x-direction sweep with the state update.
+void launch_af_rows_y(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,
+                      const double *u, const double *v, double *lo, double *di, double *up, double *rhs);
+void launch_af_sweep_x(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, double *T, const double *u,
+                       const double *rhs, double *y, double *ud, double *part, int *nparts);
 
 }  // namespace kry
 

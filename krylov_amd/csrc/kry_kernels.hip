@@ -1171,6 +1171,124 @@ __global__ __launch_bounds__(kBlock) void k_update_max(IeGeom g, double *__restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// ImplicitEulerApproxFact (include/time_disc.hpp:388-540):
+//   (I + dt Dy)(I + dt Dx) dT = dt (flux_integral + source_fd)
+// First one tridiagonal system per mesh column along y (contiguous lines: the
+// preconditioner's line solver does them), then one per mesh row along x.
+// ---------------------------------------------------------------------------
+// Lines along y in padded layout: coefficients of assemble_system_dy (:487-507)
+// and the right-hand side of :450-458.  The two ghost rows of the padded array
+// are not part of any system and become identity lines.
+__global__ __launch_bounds__(kBlock) void k_af_rows_y(IeGeom g, IeBc bc, double dt,
+                                                       const double *__restrict__ T,
+                                                       const double *__restrict__ u,
+                                                       const double *__restrict__ v,
+                                                       double *__restrict__ lo, double *__restrict__ di,
+                                                       double *__restrict__ up, double *__restrict__ rhs) {
+  const int P = g.cy + 2;
+  const int64_t nloc = (int64_t)g.rows * P;
+  const double dx = g.dx, dy = g.dy;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (int64_t)gridDim.x * kBlock) {
+    const int ip = g.row0 + (int)(k / P), jp = (int)(k % P);
+    const bool xin = ip >= 1 && ip <= g.cx, yin = jp >= 1 && jp <= g.cy;
+    double a = 0.0, d = 1.0, c = 0.0, r = 0.0;
+    if (xin && yin) {
+      const double ky = g.diffusion * g.inv_rp / dy;
+      a = (-v[k - 1] / 2.0 - ky) / dy * dt;                             // Dy_m1 * dt
+      d = 2.0 * g.diffusion * g.inv_rp / (dy * dy) * dt + 1.0;          // Dy_0 * dt + 1
+      c = (v[k + 1] / 2.0 - ky) / dy * dt;                              // Dy_p1 * dt
+      const double Tc = T[k], Tw = T[k - P], Te = T[k + P], Ts = T[k - 1], Tn = T[k + 1];
+      const double uc = u[k], uw = u[k - P], ue = u[k + P], us = u[k - 1], un = u[k + 1];
+      const double vc = v[k], vw = v[k - P], ve = v[k + P], vs = v[k - 1], vn = v[k + 1];
+      const double fx_hi = (Tc * uc + Te * ue) / 2.0;
+      const double fx_lo = (Tw * uw + Tc * uc) / 2.0;
+      const double fy_hi = (Tc * vc + Tn * vn) / 2.0;
+      const double fy_lo = (Ts * vs + Tc * vc) / 2.0;
+      const double x_deriv = (fx_hi - fx_lo) / dx;
+      const double y_deriv = (fy_hi - fy_lo) / dy;
+      const double x2_deriv = ((Te - Tc) / dx - (Tc - Tw) / dx) / dx;
+      const double y2_deriv = ((Tn - Tc) / dy - (Tc - Ts) / dy) / dy;
+      const double lapl = (x2_deriv + y2_deriv) * g.inv_rp;
+      const double flux = (-x_deriv - y_deriv) + g.diffusion * lapl;
+      const double u_dx = (ue - uw) / (2.0 * dx);
+      const double v_dy = (vn - vs) / (2.0 * dy);
+      const double u_dy = (un - us) / (2.0 * dy);
+      const double v_dx = (ve - vw) / (2.0 * dx);
+      const double cross = u_dy + v_dx;
+      const double src = g.eckert / g.reynolds * (2.0 * (u_dx * u_dx + v_dy * v_dy) + cross * cross);
+      r = (flux + src) * dt;
+    } else if (xin && jp == 0) {
+      c = 2.0 * bc.weight[KRY_SIDE_BOTTOM] - 1.0;
+    } else if (xin && jp == g.cy + 1) {
+      a = 2.0 * bc.weight[KRY_SIDE_TOP] - 1.0;
+    }
+    lo[k] = a;
+    di[k] = d;
+    up[k] = c;
+    rhs[k] = r;
+  }
+}
+
+// Lines along x (include/time_disc.hpp:466-482 with assemble_system_dx,
+// :509-529, and SparseTriDiagSolver::solve, include/solver.hpp:246-273).  One
+// lane per mesh column j walks the padded rows; neighbouring lanes touch
+// neighbouring addresses, so every access is coalesced without staging.
+// rhs holds the y-sweep's result (padded layout); y and ud are scratch.  The
+// back substitution adds the interior part of the solution to T and takes the
+// step's maximum over the solution entries 0..cx-1 of every line, the index
+// range the reference uses (its update reads entries 1..cx).
+__global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt, double *__restrict__ T,
+                                                    const double *__restrict__ u,
+                                                    const double *__restrict__ rhs, double *__restrict__ y,
+                                                    double *__restrict__ ud, double *__restrict__ part) {
+  const int P = g.cy + 2;
+  const int j = blockIdx.x * 64 + threadIdx.x;  // interior column
+  double m = 0.0;
+  if (j < g.cy) {
+    const int64_t col = j + 1;
+    const double kx = g.diffusion * g.inv_rp / g.dx;
+    const double d0 = 2.0 * g.diffusion * g.inv_rp / (g.dx * g.dx) * dt + 1.0;  // Dx_0 * dt + 1
+    // row 0: (., 1, left term), right-hand side 0
+    double vprev = 0.0 / 1.0;
+    double uprev = (2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0) / 1.0;
+    y[col] = vprev;
+    ud[col] = uprev;
+    for (int ip = 1; ip <= g.cx + 1; ip++) {
+      const int64_t k = (int64_t)ip * P + col;
+      double a, d, c, r;
+      if (ip <= g.cx) {
+        a = (-u[k - P] / 2.0 - kx) / g.dx * dt;  // Dx_m1 * dt
+        d = d0;
+        c = (u[k + P] / 2.0 - kx) / g.dx * dt;   // Dx_p1 * dt
+        r = rhs[k];
+      } else {
+        a = 2.0 * bc.weight[KRY_SIDE_RIGHT] - 1.0;
+        d = 1.0;
+        c = 0.0;
+        r = 0.0;
+      }
+      const double diag = d - uprev * a;
+      vprev = (r - vprev * a) / diag;
+      uprev = c / diag;
+      y[k] = vprev;
+      ud[k] = uprev;
+    }
+    // vprev is the final value of row cx+1
+    double next = vprev;
+    for (int ip = g.cx; ip >= 0; ip--) {
+      const int64_t k = (int64_t)ip * P + col;
+      const double x = y[k] - next * ud[k];
+      next = x;
+      if (ip >= 1) T[k] = T[k] + x;
+      if (ip <= g.cx - 1) m = nan_max(fabs(x), m);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = nan_max(m, __shfl_down(m, off, 64));
+  if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+
 __global__ __launch_bounds__(64) void k_max_final(const double *__restrict__ part, int np,
                                                    double *__restrict__ out) {
   double m = 0.0;
@@ -1448,6 +1566,19 @@ void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double 
   const int gr = grid_for(nloc);
   *nparts = gr;
   hipLaunchKernelGGL(k_update_max, dim3(gr), dim3(kBlock), 0, st, g, T, delta, part);
+}
+
+void launch_af_rows_y(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,
+                      const double *u, const double *v, double *lo, double *di, double *up, double *rhs) {
+  const int64_t nloc = (int64_t)g.rows * (g.cy + 2);
+  hipLaunchKernelGGL(k_af_rows_y, dim3(grid_for(nloc)), dim3(kBlock), 0, st, g, bc, dt, T, u, v, lo, di, up, rhs);
+}
+
+void launch_af_sweep_x(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, double *T, const double *u,
+                       const double *rhs, double *y, double *ud, double *part, int *nparts) {
+  const int gr = (g.cy + 63) / 64;
+  *nparts = gr;
+  hipLaunchKernelGGL(k_af_sweep_x, dim3(gr), dim3(64), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
 }
 
 void launch_max_final(hipStream_t st, const double *part, int nparts, double *out) {

@@ -383,3 +383,31 @@ class ImplicitEuler:
         if getattr(self, "h", None):
             capi.lib().kry_ie_destroy(self.h)
             self.h = None
+
+
+class ApproxFact(ImplicitEuler):
+    """ImplicitEulerApproxFact<SecondOrderCentered> (include/time_disc.hpp:388-540)
+    on the device: per step one tridiagonal sweep along y and one along x."""
+
+    def __init__(self, ctx, corner1, corner2, cx, cy, init, params, bcs, bc_time_dependent=True):
+        super().__init__(ctx, corner1, corner2, cx, cy, init, params, bcs, m=0,
+                         bc_time_dependent=bc_time_dependent)
+        self.apply_bcs()  # include/time_disc.hpp:440
+
+    def timestep(self, dt):
+        self._push_bc_values(self.cur_time())
+        d = C.c_double()
+        check(capi.lib().kry_ie_timestep_approx_fact(self.h, dt, C.byref(d)))
+        return d.value
+
+    def _system(self, along_y, index, dt):
+        self.apply_bcs()
+        out = np.empty(((self.cy if along_y else self.cx) + 2, 3))
+        check(capi.lib().kry_ie_get_af_system(self.h, int(along_y), index, dt, out.ctypes.data_as(_dp)))
+        return out
+
+    def assemble_system_dy(self, dt, i):
+        return self._system(True, i, dt)
+
+    def assemble_system_dx(self, dt, j):
+        return self._system(False, j, dt)

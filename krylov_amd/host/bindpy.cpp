@@ -30,7 +30,6 @@ py::object field_array(const Mesh &m, const real *data) {
 // Names that exist in the reference module but whose classes are outside the
 // device path (dense LU of the whole system, approximate factorisation).
 struct OutOfScopeLU {};
-struct OutOfScopeAF {};
 
 template <typename T> void bind_out_of_scope(py::module_ &m, const char *name, const char *why) {
   const std::string msg = std::string(name) + " is not part of this build: " + why;
@@ -162,8 +161,18 @@ PYBIND11_MODULE(krylov, module) {
 
   bind_out_of_scope<OutOfScopeLU>(module, "ImplicitEulerLUSolver",
                                   "the dense LU solve of the whole N x N system is outside the device path");
-  bind_out_of_scope<OutOfScopeAF>(module, "ImplicitEulerAFSolver",
-                                  "the approximate-factorisation integrator is outside the device path");
+  {
+    // src/bindpy.cpp:270-295
+    using AF = ImplicitEulerApproxFact<SecondOrderCentered>;
+    using P = std::pair<real, real>;
+    using BC = std::pair<BCType, BCFn>;
+    py::class_<AF, std::shared_ptr<AF>, Base>(module, "ImplicitEulerAFSolver")
+        .def(py::init<const P, const P, const size_t, const size_t, std::function<triple(real, real)>,
+                      const SecondOrderCentered &, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC>())
+        .def("timestep", &AF::timestep)
+        .def("assemble_system_dx", &AF::assemble_system_dx)
+        .def("assemble_system_dy", &AF::assemble_system_dy);
+  }
   bind_implicit_euler<GMRESSolver<10>>(module, "ImplicitEulerGMRESSolver10");
   bind_implicit_euler<GMRESSolver<20>>(module, "ImplicitEulerGMRESSolver20");
   bind_implicit_euler<GMRESSolver<30>>(module, "ImplicitEulerGMRESSolver30");

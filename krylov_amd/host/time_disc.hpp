@@ -207,4 +207,41 @@ protected:
   vector sol_vec_, delta_;
 };
 
+// include/time_disc.hpp:388-540: per step one tridiagonal sweep along y and one
+// along x, both on the device.
+template <typename SpaceDisc_> class ImplicitEulerApproxFact : public TimeDisc<SpaceDisc_> {
+public:
+  using SpaceDisc = SpaceDisc_;
+  using Base = TimeDisc<SpaceDisc_>;
+
+  template <typename... BCs>
+  ImplicitEulerApproxFact(const std::pair<real, real> corner_1, const std::pair<real, real> corner_2,
+                          const size_t cells_x, const size_t cells_y,
+                          std::function<triple(real, real)> initial_t_u_v, const SpaceDisc &space, BCs... bcs)
+      : Base(corner_1, corner_2, cells_x, cells_y, initial_t_u_v, space, bcs...) {
+    this->create_device(0, 0);  // no Krylov solver: its storage holds the line systems
+    this->apply_bcs();          // include/time_disc.hpp:440
+  }
+
+  real timestep(const real dt) {
+    this->push_bc_values();
+    real max_delta = 0.0;
+    krylov::check(kry_ie_timestep_approx_fact(this->ie_, dt, &max_delta), "kry_ie_timestep_approx_fact");
+    return max_delta;
+  }
+
+  const matrix &assemble_system_dy(const real dt, const int i) { return line_system(system_dy_, true, i, dt); }
+  const matrix &assemble_system_dx(const real dt, const int j) { return line_system(system_dx_, false, j, dt); }
+
+protected:
+  const matrix &line_system(matrix &out, const bool along_y, const int index, const real dt) {
+    this->apply_bcs();
+    const size_t rows = (along_y ? this->cur_state.cells_y() : this->cur_state.cells_x()) + 2 * Mesh::ghost_cells;
+    out = matrix(matrix::shape_type{rows, 3});
+    krylov::check(kry_ie_get_af_system(this->ie_, along_y ? 1 : 0, index, dt, out.data()), "kry_ie_get_af_system");
+    return out;
+  }
+  matrix system_dx_, system_dy_;
+};
+
 #endif  // KRYLOV_HOST_TIME_DISC_HPP_

@@ -883,6 +883,86 @@ ORC_API double orc_ie_timestep(orc_ie *s, double dt) {
   return max_delta;
 }
 
+/* ------------------------------------------------------------------------ */
+/* ImplicitEulerApproxFact, include/time_disc.hpp:388-540                    */
+/* (I + dt Dy)(I + dt Dx) dT = dt (FI + S): one tridiagonal solve per        */
+/* column along y, then one per row along x.                                 */
+/* ------------------------------------------------------------------------ */
+
+/* assemble_system_dy, include/time_disc.hpp:487-507; out is (cy+2) x 3 */
+ORC_API void orc_af_system_dy(const orc_ie *s, double dt, int i, double *out) {
+  const int rows = s->cy + 2;
+  out[0] = orc_snan();
+  out[1] = 1.0;
+  out[2] = 2.0 * s->weight[0][ORC_SIDE_BOTTOM] - 1.0;
+  out[(rows - 1) * 3 + 0] = 2.0 * s->weight[0][ORC_SIDE_TOP] - 1.0;
+  out[(rows - 1) * 3 + 1] = 1.0;
+  out[(rows - 1) * 3 + 2] = orc_snan();
+  for (int j = 1; j < rows - 1; j++) {
+    out[j * 3 + 0] = Dy_m1(s, i, j - 1) * dt;
+    out[j * 3 + 1] = Dy_0(s) * dt + 1.0;
+    out[j * 3 + 2] = Dy_p1(s, i, j - 1) * dt;
+  }
+}
+
+/* assemble_system_dx, include/time_disc.hpp:509-529; out is (cx+2) x 3 */
+ORC_API void orc_af_system_dx(const orc_ie *s, double dt, int j, double *out) {
+  const int rows = s->cx + 2;
+  out[0] = orc_snan();
+  out[1] = 1.0;
+  out[2] = 2.0 * s->weight[0][ORC_SIDE_LEFT] - 1.0;
+  out[(rows - 1) * 3 + 0] = 2.0 * s->weight[0][ORC_SIDE_RIGHT] - 1.0;
+  out[(rows - 1) * 3 + 1] = 1.0;
+  out[(rows - 1) * 3 + 2] = orc_snan();
+  for (int i = 1; i < rows - 1; i++) {
+    out[i * 3 + 0] = Dx_m1(s, i - 1, j) * dt;
+    out[i * 3 + 1] = Dx_0(s) * dt + 1.0;
+    out[i * 3 + 2] = Dx_p1(s, i - 1, j) * dt;
+  }
+}
+
+/* ImplicitEulerApproxFact::timestep, include/time_disc.hpp:443-485.  The
+ * returned maximum is taken over row_sol(i), i = 0..cx-1, i.e. WITHOUT the
+ * ghost offset that the temperature update uses (:479-480): it covers the
+ * left ghost entry and all interior cells but the last of every row. */
+ORC_API double orc_af_timestep(orc_ie *s, double dt) {
+  const int cx = s->cx, cy = s->cy;
+  const int ny = cy + 2, nx = cx + 2;
+  const int nmax = nx > ny ? nx : ny;
+  double *sys = (double *)malloc(sizeof(double) * 3 * (size_t)nmax);
+  double *rhs = (double *)malloc(sizeof(double) * (size_t)nmax);
+  double *sol = (double *)malloc(sizeof(double) * (size_t)nmax);
+  double *ud = (double *)malloc(sizeof(double) * (size_t)nmax);
+  double *partial = (double *)malloc(sizeof(double) * (size_t)cx * cy);
+  orc_ie_apply_bcs(s);
+  for (int i = 0; i < cx; i++) {
+    orc_af_system_dy(s, dt, i, sys);
+    rhs[0] = 0.0;
+    rhs[ny - 1] = 0.0;
+    for (int j = 0; j < cy; j++) {
+      rhs[j + 1] = (orc_flux_integral(s, i, j) + orc_source_fd(s, i, j)) * dt;
+    }
+    orc_sparse_tridiag_solve(sys, rhs, sol, ud, ny);
+    for (int j = 0; j < cy; j++) partial[(size_t)i * cy + j] = sol[j + 1];
+  }
+  double max_delta = 0.0;
+  for (int j = 0; j < cy; j++) {
+    orc_af_system_dx(s, dt, j, sys);
+    rhs[0] = 0.0;
+    rhs[nx - 1] = 0.0;
+    for (int i = 0; i < cx; i++) rhs[i + 1] = partial[(size_t)i * cy + j];
+    orc_sparse_tridiag_solve(sys, rhs, sol, ud, nx);
+    for (int i = 0; i < cx; i++) {
+      const double a = fabs(sol[i]);
+      max_delta = (a < max_delta) ? max_delta : a; /* std::max(a, max_delta) */
+      AT(s, 0, i, j) += sol[i + 1];
+    }
+  }
+  s->time += dt;
+  free(sys); free(rhs); free(sol); free(ud); free(partial);
+  return max_delta;
+}
+
 ORC_API double orc_ie_time(const orc_ie *s) { return s->time; }
 ORC_API long orc_ie_num_eqns(const orc_ie *s) { return s->n; }
 ORC_API int64_t orc_ie_nnz(const orc_ie *s) { return s->rowptr[s->n]; }

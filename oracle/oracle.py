@@ -86,6 +86,9 @@ def lib():
     sig("orc_ie_init_offdiag", None, _vp)
     sig("orc_ie_assemble_system", None, _vp, C.c_double)
     sig("orc_ie_timestep", C.c_double, _vp, C.c_double)
+    sig("orc_af_system_dy", None, _vp, C.c_double, C.c_int, _dp)
+    sig("orc_af_system_dx", None, _vp, C.c_double, C.c_int, _dp)
+    sig("orc_af_timestep", C.c_double, _vp, C.c_double)
     sig("orc_ie_time", C.c_double, _vp)
     sig("orc_ie_num_eqns", C.c_long, _vp)
     sig("orc_ie_nnz", C.c_int64, _vp)
@@ -449,3 +452,25 @@ class ImplicitEuler:
         if getattr(self, "h", None):
             lib().orc_ie_free(self.h)
             self.h = None
+
+
+class ApproxFact(ImplicitEuler):
+    """ImplicitEulerApproxFact<SecondOrderCentered> (include/time_disc.hpp:388-540)."""
+
+    def __init__(self, corner1, corner2, cx, cy, init, params, bcs):
+        super().__init__(corner1, corner2, cx, cy, init, params, bcs, m=1)
+        self.apply_bcs()  # include/time_disc.hpp:440
+
+    def timestep(self, dt):
+        self._push_bc_values(self.cur_time())
+        return lib().orc_af_timestep(self.h, dt)
+
+    def assemble_system_dy(self, dt, i):
+        out = np.empty((self.cy + 2, 3))
+        lib().orc_af_system_dy(self.h, dt, i, out.ctypes.data_as(_dp))
+        return out
+
+    def assemble_system_dx(self, dt, j):
+        out = np.empty((self.cx + 2, 3))
+        lib().orc_af_system_dx(self.h, dt, j, out.ctypes.data_as(_dp))
+        return out
