@@ -150,20 +150,22 @@ def main():
     #  their per-class averages do not describe the sweep, so no roofline entry there)
     if "mgs_block_full" in kernels and not ext_stats:
         k = kernels["mgs_block_full"]
-        # one full Gram-Schmidt sweep: w read + written, 4 basis vectors applied,
-        # 4 basis vectors dotted: 10 x 8 B per unknown
-        per_launch = 80.0 * N
+        # one full Gram-Schmidt sweep: w read + written, K basis vectors applied,
+        # K basis vectors dotted: (2 + 2 K) x 8 B per unknown
+        K = dev.solver().get_mgs_block()
+        per_launch = (2.0 + 2.0 * K) * 8.0 * N
         achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("mesh") == n_side:
+                if tj.get("mesh") == n_side and tj.get("mgs_block") == K:
                     traffic = tj.get("mgs_block_full_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,1> (Gram-Schmidt sweep: 4 projections applied + 4 dots)",
+        roofline = {"bound": "hbm", "kernel": "k_mgs_block<%d,%d,false,1> (Gram-Schmidt sweep: %d projections applied + %d dots, "
+                              "%d B per unknown)" % (K, K, K, K, 16 + 16 * K),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],

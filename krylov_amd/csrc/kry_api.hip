@@ -181,7 +181,7 @@ struct kry_gmres {
   bool offset_applied = false;  // w / vars / z already point past their front halo
   double *tot = nullptr;  // kMaxRed totals handed to the all-reduce
   int m = 0, flags = 0;
-  int kblock = kMgsBlock;  // Gram-Schmidt links fused per sweep (1 = the plain chain)
+  int kblock = 4;  // Gram-Schmidt links fused per sweep (1 = the plain chain), <= kMgsBlock
   int nvec = 0;  // subspace.size()
   double *V = nullptr;      // (m+1) x ld
   double *H = nullptr;      // (m+1) x m
@@ -678,6 +678,10 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   g->ld = g->halo + (n + 31) / 32 * 32 + g->halo;
   g->m = m;
   g->flags = flags;
+  // Eight links per sweep move 18 bytes per unknown and link instead of 20 and halve the
+  // number of reductions (all-reduces on several ranks); below about two million unknowns
+  // the longer prologue (36 partial-sum arrays) costs more than that saves.
+  g->kblock = (n >= (int64_t(1) << 21) || ctx->nranks > 1) ? 8 : 4;
   if (const char *e = getenv("KRY_MGS_BLOCK")) {  // experimentation knob, same range as the setter
     const int k = atoi(e);
     if (k >= 1 && k <= kMgsBlock) g->kblock = k;
@@ -889,7 +893,7 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   for (int cs = kp; cs < nv; cs += K, cur++) {
     const int kc = nv - cs < K ? nv - cs : K;
     {
-      ScopedKernelTimer t(g->ctx, (kp == kMgsBlock && kc == kMgsBlock) ? KRY_K_MGS : KRY_K_MGS_PART);
+      ScopedKernelTimer t(g->ctx, (kp == K && kc == K) ? KRY_K_MGS : KRY_K_MGS_PART);
       launch_mgs_block(st, kp, kc, g->w, basis(g, ps), basis(g, cs), g->ld, pin, npin, part[cur & 1],
                        &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
     }
@@ -1156,7 +1160,7 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     launches[KRY_K_SPMV] += 1;
     for (int cs = kp; cs < nv; cs += K) {
       const int kc = nv - cs < K ? nv - cs : K;
-      const int cls = (kp == kMgsBlock && kc == kMgsBlock) ? KRY_K_MGS : KRY_K_MGS_PART;
+      const int cls = (kp == K && kc == K) ? KRY_K_MGS : KRY_K_MGS_PART;
       bytes[cls] += (2.0 + kp + kc) * N;  // w read + written, kp applied, kc dotted
       launches[cls] += 1;
       kp = kc;

@@ -13,7 +13,7 @@ constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups
 constexpr int kMaxParts = 2048;    // partial sums per reduction buffer
 constexpr int kMaxM = 256;         // largest Krylov dimension supported
-constexpr int kMgsBlock = 4;       // most Gram-Schmidt links fused into one sweep over w
+constexpr int kMgsBlock = 8;       // most Gram-Schmidt links fused into one sweep over w
 constexpr int kMaxRed = kMgsBlock + kMgsBlock * (kMgsBlock - 1) / 2;  // partial-sum arrays per pass
 
 // Five coefficient bands of a stencil operator on a rows x cols padded grid.

@@ -1309,14 +1309,21 @@ void launch_fill(hipStream_t st, double *x, double v, int64_t n) {
 // Launch shape of a streaming sweep over `streams` arrays.  Measured on
 // MI355X: HBM efficiency is best when the number of concurrently advancing
 // stream heads (streams x workgroups) stays near the number of DRAM banks
-// (~4096) and the grid is a multiple of the 256 CUs; wide sweeps want one
-// 16-byte element per lane and stream in flight, narrow ones four.
+// (~4096); above 256 workgroups the grid must be a multiple of the 256 CUs
+// (384 is slower than both 256 and 512), below that any count works (224 beats
+// 256 for 18 streams); wide sweeps want one 16-byte element per lane and
+// stream in flight, narrow ones four.
 constexpr int sweep_unroll(int streams) { return streams >= 8 ? 1 : (streams >= 5 ? 2 : 4); }
 
 int sweep_grid(int64_t n2, int streams, int unroll) {
-  int64_t g = 4096 / streams / 256 * 256;
-  if (g < 256) g = 256;
-  if (g > 1024) g = 1024;
+  int64_t g = 4096 / streams;
+  if (g >= 256) {
+    g = g / 256 * 256;  // whole waves of workgroups over the 256 CUs: no CU gets an extra one
+    if (g > 1024) g = 1024;
+  } else {
+    g = g / 8 * 8;  // fewer workgroups than CUs: all resident at once, spread evenly over the 8 XCDs
+    if (g < 64) g = 64;
+  }
   const int64_t tiles = (n2 + (int64_t)kBlock * unroll - 1) / ((int64_t)kBlock * unroll);
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
@@ -1361,16 +1368,27 @@ static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int
     hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop);
 }
 
+// kc -> template argument (0..kMgsBlock)
+template <bool HALO, int KC = kMgsBlock>
+struct SpmvStencilKc {
+  static void go(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x, double *y, int kc,
+                 const double *cbase, int64_t ld, double *part, int *nparts) {
+    if (kc == KC)
+      launch_spmv_stencil_t<KC, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts);
+    else
+      SpmvStencilKc<HALO, KC - 1>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+  }
+};
+template <bool HALO>
+struct SpmvStencilKc<HALO, -1> {
+  static void go(hipStream_t, const Bands &, int64_t, int, const double *, double *, int, const double *, int64_t,
+                 double *, int *) {}
+};
+
 template <bool HALO>
 static void launch_spmv_stencil_h(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                                   double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
-  switch (kc) {
-    case 0: launch_spmv_stencil_t<0, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    case 1: launch_spmv_stencil_t<1, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    case 2: launch_spmv_stencil_t<2, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    case 3: launch_spmv_stencil_t<3, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-    default: launch_spmv_stencil_t<4, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts); break;
-  }
+  SpmvStencilKc<HALO>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
 }
 
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
@@ -1395,16 +1413,26 @@ static void launch_spmv_csr_t(hipStream_t st, const int64_t *rowptr, const int32
   hipLaunchKernelGGL((k_spmv_csr<KC>), dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, cbase, ld, part, t_stop);
 }
 
+template <int KC = kMgsBlock>
+struct SpmvCsrKc {
+  static void go(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val, int64_t n,
+                 const double *x, double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
+    if (kc == KC)
+      launch_spmv_csr_t<KC>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts);
+    else
+      SpmvCsrKc<KC - 1>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts);
+  }
+};
+template <>
+struct SpmvCsrKc<-1> {
+  static void go(hipStream_t, const int64_t *, const int32_t *, const double *, int64_t, const double *, double *, int,
+                 const double *, int64_t, double *, int *) {}
+};
+
 void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
                      int64_t n, const double *x, double *y, int kc, const double *cbase, int64_t ld,
                      double *part, int *nparts) {
-  switch (kc) {
-    case 0: launch_spmv_csr_t<0>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
-    case 1: launch_spmv_csr_t<1>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
-    case 2: launch_spmv_csr_t<2>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
-    case 3: launch_spmv_csr_t<3>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
-    default: launch_spmv_csr_t<4>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts); break;
-  }
+  SpmvCsrKc<>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts);
 }
 
 template <int KP, int KC, bool NORM>
@@ -1419,28 +1447,45 @@ static void launch_mgs_block_t(hipStream_t st, double *w, const double *pbase, c
                      part_in, np_in, part_out, hout, hstride, n, t_stop);
 }
 
-template <int KP>
-static void launch_mgs_block_kp(hipStream_t st, int kc, double *w, const double *pbase,
-                                const double *cbase, int64_t ld, const double *part_in, int np_in,
-                                double *part_out, int *np_out, double *hout, int hstride, int64_t n) {
-  switch (kc) {
-    case 0: launch_mgs_block_t<KP, 0, true>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    case 1: launch_mgs_block_t<KP, 1, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    case 2: launch_mgs_block_t<KP, 2, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    case 3: launch_mgs_block_t<KP, 3, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    default: launch_mgs_block_t<KP, 4, false>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
+// (kp, kc) -> template arguments (kp 1..kMgsBlock, kc 0..kMgsBlock; kc == 0 is the norm pass)
+template <int KP, int KC = kMgsBlock>
+struct MgsKc {
+  static void go(hipStream_t st, int kc, double *w, const double *pbase, const double *cbase, int64_t ld,
+                 const double *part_in, int np_in, double *part_out, int *np_out, double *hout, int hstride,
+                 int64_t n) {
+    if (kc == KC)
+      launch_mgs_block_t<KP, KC, KC == 0>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+    else
+      MgsKc<KP, KC - 1>::go(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
   }
-}
+};
+template <int KP>
+struct MgsKc<KP, -1> {
+  static void go(hipStream_t, int, double *, const double *, const double *, int64_t, const double *, int, double *,
+                 int *, double *, int, int64_t) {}
+};
+
+template <int KP = kMgsBlock>
+struct MgsKp {
+  static void go(hipStream_t st, int kp, int kc, double *w, const double *pbase, const double *cbase, int64_t ld,
+                 const double *part_in, int np_in, double *part_out, int *np_out, double *hout, int hstride,
+                 int64_t n) {
+    if (kp == KP)
+      MgsKc<KP>::go(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+    else
+      MgsKp<KP - 1>::go(st, kp, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+  }
+};
+template <>
+struct MgsKp<0> {
+  static void go(hipStream_t, int, int, double *, const double *, const double *, int64_t, const double *, int,
+                 double *, int *, double *, int, int64_t) {}
+};
 
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
                       double *part_out, int *np_out, double *hout, int hstride, int64_t n) {
-  switch (kp) {
-    case 1: launch_mgs_block_kp<1>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    case 2: launch_mgs_block_kp<2>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    case 3: launch_mgs_block_kp<3>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-    default: launch_mgs_block_kp<4>(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n); break;
-  }
+  MgsKp<>::go(st, kp, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
 }
 
 void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,

@@ -103,9 +103,10 @@ def run(args, world, rank, local_rank, out_stream=None):
         roofline = None
         if "mgs_block_full" in kernels:
             k = kernels["mgs_block_full"]
-            per_launch = 80.0 * nloc
+            K = dev.solver().get_mgs_block()
+            per_launch = (2.0 + 2.0 * K) * 8.0 * nloc
             achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_mgs_block<4,4,false,1> on rank 0's row block",
+            roofline = {"bound": "hbm", "kernel": "k_mgs_block<%d,%d,false,1> on rank 0's row block" % (K, K),
                         "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": None,
                         "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],

@@ -182,6 +182,9 @@ class GMRESSolver:
     def set_mgs_block(self, k):
         check(capi.lib().kry_gmres_set_mgs_block(self.h, k))
 
+    def get_mgs_block(self):
+        return capi.lib().kry_gmres_get_mgs_block(self.h)
+
     def cycle_bytes(self, op):
         b = (C.c_double * capi.K_COUNT)()
         l = (C.c_int * capi.K_COUNT)()

@@ -337,6 +337,15 @@ int main(int argc, char **argv) {
       snprintf(nm, sizeof nm, "VK 6+6 U1 G%d (112 B)", G); run(nm, 112, [&](int r) { hipLaunchKernelGGL((vk<256, 1, 6>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
       snprintf(nm, sizeof nm, "VK 8+8 U1 G%d (144 B)", G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vk<256, 1, 8>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
     }
+    // launch-shape variants of the 8+8 sweep
+    for (int G : {128, 256, 512}) {
+      snprintf(nm, sizeof nm, "VK 8+8 BLK512 U1 G%d (144 B)", G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vk<512, 1, 8>), dim3(G), dim3(512), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VK 8+8 BLK128 U1 G%d (144 B)", 2 * G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vk<128, 1, 8>), dim3(2 * G), dim3(128), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VK 8+8 BLK256 U2 G%d (144 B)", G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vk<256, 2, 8>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+    }
+    for (int G : {224, 240, 256, 272, 288, 320}) {
+      snprintf(nm, sizeof nm, "VK 8+8 U1 G%d (144 B)", G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vk<256, 1, 8>), dim3(G), dim3(256), 0, 0, big, big + ld, big + 9 * ld, ld, part, n2); });
+    }
     return 0;
   }
   run("V1 single link NT U4 G1024 (ref)", 32, [&](int r) { hipLaunchKernelGGL((v1<256, 4, true>), dim3(1024), dim3(256), 0, 0, v[0], P(r), Cc(r), 1e-3, part, n2); });
