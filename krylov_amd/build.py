@@ -74,9 +74,26 @@ def build_pybind(force=False, verbose=False):
     return out
 
 
+def build_c_example(force=False, verbose=False):
+    """examples/step_loop.c: a plain C99 caller of the C ABI (gcc, no C++)."""
+    src = os.path.join(ROOT, "examples", "step_loop.c")
+    if not os.path.exists(src):
+        return None
+    out = os.path.join(ROOT, "examples", "step_loop")
+    if not force and _newer(out, [src, os.path.join(ROOT, "include", "krylov_amd.h")]) and _newer(out, [LIB]):
+        return out
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+           "-L" + PKG, "-lkrylov_amd", "-Wl,-rpath,$ORIGIN/../krylov_amd", "-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
     build_lib(force, verbose)
     build_pybind(force, verbose)
+    build_c_example(force, verbose)
 
 
 if __name__ == "__main__":

@@ -59,3 +59,19 @@ def test_null_arguments_are_rejected():
     assert L.kry_gmres_solve(None, None, None, None) != capi.OK
     assert L.kry_ie_timestep(None, 0.25, None) != capi.OK
     assert L.kry_op_size(None) == 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/krylov_amd.h compiles as C99 with -pedantic (no C++ or HIP types in the boundary)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "krylov_amd.h"\nint main(void) { return kry_version() == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+
+
+def test_c_example_links_against_the_library():
+    """examples/step_loop.c (plain C caller of the C ABI) builds and resolves its symbols."""
+    from krylov_amd import build
+    exe = build.build_c_example()
+    assert exe and os.path.exists(exe)

@@ -498,3 +498,20 @@ def test_line_preconditioner_general_matrix_bit_exact(ctx, oracle):
     diags = ref.assemble_preconditioner(oracle.Op.dense(A))
     v = rng.uniform(-1.0, 1.0, n)
     assert np.array_equal(g.apply_preconditioner(v), oracle.sparse_tridiag_solve(diags, v))
+
+
+def test_c_caller_reproduces_recorded_reference_run():
+    """examples/step_loop.c, a C99 program on the C ABI alone, replays the
+    prob1 time loop with GMRESSolver<10>: the reference needs 147 steps and ends
+    on a summed interior temperature of 528.465360608386."""
+    import subprocess
+    from krylov_amd import build
+    exe = build.build_c_example()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    words = out.stdout.split()
+    run = [r for r in json.load(open(os.path.join(HERE, "golden", "prob1_reference_runs.json")))["runs"]
+           if r["solver"] == "GMRESSolver" and r["m"] == 10][0]
+    assert int(words[1]) == run["steps_to_1e-9"]
+    assert abs(float(words[5]) - run["sum_T_interior"]) <= 1e-10 * run["sum_T_interior"]
+    assert float(words[7]) == 0.25 * run["steps_to_1e-9"]
