@@ -125,6 +125,9 @@ def run(args, world, rank, local_rank, out_stream=None):
                        "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
                        "parallelism": "row blocks over %d GPUs (halo rows + all-reduced dots, %s)" % (world, backend),
                        "rows_per_rank": [b - a for a, b in ranges]},
+            # algorithmic bytes of rank 0's row block, scaled to the whole job (blocks differ by at most one row)
+            "hbm_gbps_whole_job": round(world * sum(bytes_cycle) * args.steps / elapsed / 1e9, 1),
+            "hbm_frac_whole_job": round(sum(bytes_cycle) * args.steps / elapsed / 1e9 / 8000.0, 4),
             "last_max_delta": last,
             "rank0_kernel_ms_per_step": round(kernel_ms / args.steps, 2),
             "rank0_comm_and_gap_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms / args.steps, 2),
