@@ -272,6 +272,41 @@ __global__ __launch_bounds__(BLK) void vk(double *w, const double *pbase, const 
   for (int q = 0; q < NQ; q++) { double t = block_sum<BLK>(acc[q], s); if (threadIdx.x == 0) part[q * gridDim.x + blockIdx.x] = t; }
 }
 
+// VD: K links per pass without Gram entries (2K+1 reads, 1 write, K dots + 1 extra dot)
+template <int BLK, int U, int K>
+__global__ __launch_bounds__(BLK) void vd(double *w, const double *pbase, const double *cbase, long ld, double *part, long n2) {
+  __shared__ double s[BLK / 64];
+  d2 *w2 = (d2 *)w;
+  double acc[K];
+#pragma unroll
+  for (int q = 0; q < K; q++) acc[q] = 0.0;
+  double h[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) h[k] = 1e-3 * (k + 1);
+  const long tile = (long)BLK * U;
+  for (long base = (long)blockIdx.x * tile; base < n2; base += (long)gridDim.x * tile) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long i = base + u * BLK + threadIdx.x;
+      if (i < n2) {
+        d2 r = __builtin_nontemporal_load(&w2[i]);
+        d2 pv[K], cv[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) pv[k] = __builtin_nontemporal_load((const d2 *)(pbase + k * ld) + i);
+#pragma unroll
+        for (int k = 0; k < K; k++) cv[k] = __builtin_nontemporal_load((const d2 *)(cbase + k * ld) + i);
+#pragma unroll
+        for (int k = 0; k < K; k++) r = r - h[k] * pv[k];
+        __builtin_nontemporal_store(r, &w2[i]);
+#pragma unroll
+        for (int a = 0; a < K; a++) { acc[a] = fma(r.x, cv[a].x, acc[a]); acc[a] = fma(r.y, cv[a].y, acc[a]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < K; q++) { double t = block_sum<BLK>(acc[q], s); if (threadIdx.x == 0) part[q * gridDim.x + blockIdx.x] = t; }
+}
+
 // plain copy for calibration
 template <int BLK, int U, bool NT>
 __global__ __launch_bounds__(BLK) void vcopy(double *w, const double *p, long n2) {
@@ -330,6 +365,15 @@ int main(int argc, char **argv) {
   // vectors with leading dimension ld for the K+K sweeps
   double *big; const long ld = (n + 31) / 32 * 32;
   CHECK(hipMalloc((void **)&big, sizeof(double) * ld * 17)); CHECK(hipMemset(big, 0, sizeof(double) * ld * 17));
+  if (argc > 2 && !strcmp(argv[2], "wide16")) {
+    double *big2; CHECK(hipMalloc((void **)&big2, sizeof(double) * ld * 33)); CHECK(hipMemset(big2, 0, sizeof(double) * ld * 33));
+    for (int G : {96, 112, 120, 128, 192, 256}) {
+      snprintf(nm, sizeof nm, "VD 8+8 dots only U1 G%d (144 B)", 2 * G); run(nm, 144, [&](int r) { hipLaunchKernelGGL((vd<256, 1, 8>), dim3(2 * G), dim3(256), 0, 0, big2, big2 + ld, big2 + 17 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VD 16+16 dots only U1 G%d (272 B)", G); run(nm, 272, [&](int r) { hipLaunchKernelGGL((vd<256, 1, 16>), dim3(G), dim3(256), 0, 0, big2, big2 + ld, big2 + 17 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VD 16+16 dots only BLK512 G%d (272 B)", G); run(nm, 272, [&](int r) { hipLaunchKernelGGL((vd<512, 1, 16>), dim3(G), dim3(512), 0, 0, big2, big2 + ld, big2 + 17 * ld, ld, part, n2); });
+    }
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "wide")) {
     // bytes per link: K=4: 20, K=6: 18.7, K=8: 18
     for (int G : {128, 192, 256, 384, 512}) {
