@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the round's evidence for the default benchmark configuration on one MI355X:
+# Collects the measured evidence for the default benchmark configuration on one MI355X:
 #  1. the bench line itself (with cpu_baseline),
 #  2. rocprofv3 --kernel-trace --stats of the same command (without the CPU sample),
 #  3. FETCH_SIZE and WRITE_SIZE in two separate counter passes over one step.
