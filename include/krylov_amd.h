@@ -72,6 +72,8 @@ int kry_device_count(int *count);
 int kry_ctx_create(int device, void *stream, kry_ctx **out);
 void kry_ctx_destroy(kry_ctx *ctx);
 int kry_ctx_synchronize(kry_ctx *ctx);
+/* Free and total memory of the context's device in bytes (either may be NULL). */
+int kry_ctx_memory_info(kry_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* hipStream_t of the context (for event timing by the caller). */
 void *kry_ctx_stream(kry_ctx *ctx);
 /* Row-block decomposition over several processes (one per GPU).  The library

@@ -32,6 +32,7 @@ SIGNATURES = {
     "kry_ctx_synchronize": (C.c_int, [_vp]),
     "kry_ctx_stream": (_vp, [_vp]),
     "kry_ctx_set_comm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "kry_ctx_memory_info": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "kry_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "kry_ctx_set_comm_rccl": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "kry_ctx_comm_is_native": (C.c_int, [_vp]),

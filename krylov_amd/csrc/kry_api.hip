@@ -361,6 +361,16 @@ int kry_ctx_set_comm_rccl(kry_ctx *ctx, int rank, int nranks, const unsigned cha
 
 int kry_ctx_comm_is_native(const kry_ctx *ctx) { return ctx && ctx->nccl ? 1 : 0; }
 
+int kry_ctx_memory_info(kry_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes) {
+  if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return KRY_OK;
+}
+
 int kry_ctx_rank(const kry_ctx *ctx) { return ctx ? ctx->rank : 0; }
 int kry_ctx_nranks(const kry_ctx *ctx) { return ctx ? ctx->nranks : 1; }
 

@@ -32,6 +32,12 @@ class Context:
         check(capi.lib().kry_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
 
+    def memory_info(self):
+        """(free, total) bytes of the device."""
+        f, t = C.c_int64(), C.c_int64()
+        check(capi.lib().kry_ctx_memory_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def synchronize(self):
         check(capi.lib().kry_ctx_synchronize(self.h))
 
