@@ -5,6 +5,7 @@ is visible, the calls raise.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkrylov_amd.so")
@@ -120,6 +121,15 @@ def lib():
         raise KrylovError(
             "%s is missing: build it with `python -m krylov_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # PyTorch wheels bundle their own HIP runtime.  If this library brought the system
+    # runtime into the process first, a later `import torch` would add a second one and
+    # PyTorch would see no GPU; importing torch first (when it is installed) makes the
+    # two share one runtime.  KRY_NO_TORCH_PRELOAD=1 skips this.
+    if "torch" not in sys.modules and not os.environ.get("KRY_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001 - absent or broken PyTorch is not this library's concern
+            pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(L, name)
