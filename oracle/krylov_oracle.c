@@ -58,6 +58,18 @@ ORC_API void orc_dense_matmul(double *res, const double *lhs, const double *rhs,
   }
 }
 
+/* Timing-only variant: with -DORC_OPENMP -fopenmp the vector-length loops of
+ * the GMRES path run on all threads (libkrylov_oracle_omp.so, used for the
+ * all-cores CPU baseline of the benchmark).  Reductions then sum in a different
+ * order, so that build is never used as the parity checker. */
+#ifdef ORC_OPENMP
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static)")
+#define ORC_PAR_SUM(var) _Pragma("omp parallel for schedule(static) reduction(+ : acc)")
+#else
+#define ORC_PAR_FOR
+#define ORC_PAR_SUM(var)
+#endif
+
 /* dot(vector&, const matrix&, const vector&), include/matrix.hpp:23-33 */
 ORC_API void orc_dense_matvec(double *res, const double *a, const double *x,
                               long rows, long cols) {
@@ -75,6 +87,7 @@ ORC_API void orc_dense_matvec(double *res, const double *a, const double *x,
 ORC_API void orc_csr_matvec(double *res, const int64_t *rowptr,
                             const int32_t *col, const double *val,
                             const double *x, long n) {
+  ORC_PAR_FOR
   for (long i = 0; i < n; i++) {
     double acc = 0.0;
     for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) {
@@ -87,6 +100,7 @@ ORC_API void orc_csr_matvec(double *res, const int64_t *rowptr,
 /* dot(real&, const vector&, const vector&), include/matrix.hpp:35-44 */
 ORC_API double orc_dot(const double *lhs, const double *rhs, long n) {
   double acc = 0.0;
+  ORC_PAR_SUM(acc)
   for (long i = 0; i < n; i++) {
     acc += lhs[i] * rhs[i];
   }
@@ -95,16 +109,18 @@ ORC_API double orc_dot(const double *lhs, const double *rhs, long n) {
 
 /* l2_norm, include/matrix.hpp:46-52 */
 ORC_API double orc_l2_norm(const double *v, long n) {
-  double l2 = 0.0;
+  double acc = 0.0;
+  ORC_PAR_SUM(acc)
   for (long i = 0; i < n; i++) {
-    l2 += v[i] * v[i];
+    acc += v[i] * v[i];
   }
-  return sqrt(l2);
+  return sqrt(acc);
 }
 
 /* normalize, include/matrix.hpp:54-60 (true division, not a reciprocal) */
 ORC_API double orc_normalize(double *v, long n) {
   const double l2 = orc_l2_norm(v, n);
+  ORC_PAR_FOR
   for (long i = 0; i < n; i++) {
     v[i] /= l2;
   }
@@ -350,6 +366,7 @@ static void orc_gram_schmidt(orc_gmres *g, double *next) {
     const double *v = g->V + (size_t)i * n;
     const double h = orc_dot(next, v, n);
     g->H[i * m + j] = h;
+    ORC_PAR_FOR
     for (long k = 0; k < n; k++) {
       next[k] -= h * v[k];
     }
@@ -411,6 +428,7 @@ ORC_API const double *orc_gmres_solve(orc_gmres *g, const orc_op *op,
   for (int i = 0; i < m; i++) {
     const double *dim = g->V + (size_t)i * n;
     const double s = g->y[i];
+    ORC_PAR_FOR
     for (long k = 0; k < n; k++) {
       g->vars[k] += s * dim[k];
     }
