@@ -521,3 +521,50 @@ def test_c_caller_reproduces_recorded_reference_run():
     assert int(words[1]) == run["steps_to_1e-9"]
     assert abs(float(words[5]) - run["sum_T_interior"]) <= 1e-10 * run["sum_T_interior"]
     assert float(words[7]) == 0.25 * run["steps_to_1e-9"]
+
+
+# ---- randomised configurations -----------------------------------------------------------
+
+def _random_problem(seed):
+    """A seeded random configuration: mesh shape (incl. single-cell rows and
+    columns), domain corners in either order, every mix of Dirichlet / Neumann
+    conditions, rough fields, time-dependent boundary values."""
+    rng = np.random.default_rng(seed)
+    cx, cy = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    c1 = (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)))
+    c2 = (c1[0] + float(rng.choice([-1, 1]) * rng.uniform(0.5, 30)), c1[1] + float(rng.choice([-1, 1]) * rng.uniform(0.5, 3)))
+    coef = rng.uniform(-1, 1, (3, 4))
+
+    def init(x, y):
+        return tuple(coef[f, 0] * np.sin(coef[f, 1] * 3 * x + y) + coef[f, 2] * np.cos(x - coef[f, 3] * 2 * y) for f in range(3))
+
+    bcs = {}
+    for f in range(3):
+        for s in range(4):
+            a, b, c = rng.uniform(-1, 1, 3)
+            bcs[(f, s)] = (bool(rng.integers(0, 2)), (lambda a, b, c: lambda x, y, t: a * x + b * y + c * t)(a, b, c))
+    params = (float(rng.uniform(0.2, 2)), float(rng.uniform(5, 50)), float(rng.uniform(0.5, 1)), float(rng.uniform(0.05, 0.3)))
+    return dict(corner1=c1, corner2=c2, cx=cx, cy=cy, init=init, params=params, bcs=bcs), float(rng.uniform(0.05, 0.5))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations(ctx, oracle, seed):
+    """Ghost fill, operator bands and right-hand side bit for bit, then three
+    steps (one fixed cycle each) against the restatement."""
+    prob, dt = _random_problem(seed)
+    m = 6
+    ref = oracle.ImplicitEuler(**prob, m=m)
+    dev = host.ImplicitEuler(ctx, **prob, m=m)
+    ref.assemble_system(dt)
+    dev.assemble_system(dt)
+    for f in range(3):
+        assert np.array_equal(dev.field(f), ref.field(f), equal_nan=True)
+    assert np.array_equal(dev.sol_vec(), ref.sol_vec())
+    if ref.n <= 400:
+        assert np.array_equal(dev.dense_system(), ref.dense_system())
+    for _ in range(3):
+        d, dr = dev.timestep(dt), ref.timestep(dt)
+        assert abs(d - dr) <= 1e-9 * abs(dr) + 1e-13
+    T, Tr = dev.field(0)[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]
+    assert rel(T, Tr) <= 1e-9
+    assert dev.cur_time() == ref.cur_time()
