@@ -171,11 +171,11 @@ int kry_gmres_prev_result(kry_gmres *g, double *out_host);
 /* Device pointer to the n-entry result vector. */
 const double *kry_gmres_result_device(kry_gmres *g);
 /* Number of modified-Gram-Schmidt links fused into one sweep over the work
- * vector, 1..8 (default: 8 from about two million unknowns per rank on or on
- * several ranks, else 4).  1 is the reference's plain chain, one link per
+ * vector, 1..16 (default 16).  1 is the reference's plain chain, one link per
  * sweep (include/solver.hpp:198-207); larger groups take the group's dot
  * products in one pass and recover the same coefficients through the group's
- * Gram entries, h_k = <w, v_k> - sum_{a<k} h_a <v_a, v_k>. */
+ * Gram entries, h_k = <w, v_k> - sum_{a<k} h_a <v_a, v_k>, which are computed
+ * once, in the step that creates v_k, and carried in a small matrix. */
 int kry_gmres_set_mgs_block(kry_gmres *g, int k);
 int kry_gmres_get_mgs_block(const kry_gmres *g);
 int64_t kry_gmres_size(const kry_gmres *g);

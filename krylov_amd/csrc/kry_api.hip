@@ -180,8 +180,9 @@ struct kry_gmres {
   int64_t halo = 0, halo_row = 0;
   bool offset_applied = false;  // w / vars / z already point past their front halo
   double *tot = nullptr;  // kMaxRed totals handed to the all-reduce
+  double *G = nullptr;    // (m+1) x (m+1) Gram entries <v_a, v_b> of basis vectors in the same group, a < b
   int m = 0, flags = 0;
-  int kblock = 4;  // Gram-Schmidt links fused per sweep (1 = the plain chain), <= kMgsBlock
+  int kblock = kMgsBlock;  // Gram-Schmidt links fused per sweep (1 = the plain chain), <= kMgsBlock
   int nvec = 0;  // subspace.size()
   double *V = nullptr;      // (m+1) x ld
   double *H = nullptr;      // (m+1) x m
@@ -688,10 +689,10 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   g->ld = g->halo + (n + 31) / 32 * 32 + g->halo;
   g->m = m;
   g->flags = flags;
-  // Eight links per sweep move 18 bytes per unknown and link instead of 20 and halve the
-  // number of reductions (all-reduces on several ranks); below about two million unknowns
-  // the longer prologue (36 partial-sum arrays) costs more than that saves.
-  g->kblock = (n >= (int64_t(1) << 21) || ctx->nranks > 1) ? 8 : 4;
+  // Sixteen links per sweep: 17 bytes per unknown and link (the limit for ever larger
+  // groups is 16) and a sixteenth of the reductions (all-reduces on several ranks) of the
+  // plain chain; measured fastest at every mesh size from 1024^2 to 8192^2.
+  g->kblock = kMgsBlock;
   if (const char *e = getenv("KRY_MGS_BLOCK")) {  // experimentation knob, same range as the setter
     const int k = atoi(e);
     if (k >= 1 && k <= kMgsBlock) g->kblock = k;
@@ -703,6 +704,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   if (st == KRY_OK) st = dev_alloc(&g->vars, g->ld);
   if (st == KRY_OK) st = dev_alloc(&g->parts, 2 * (int64_t)kMaxRed * kMaxParts);
   if (st == KRY_OK) st = dev_alloc(&g->tot, kMaxRed);
+  if (st == KRY_OK) st = dev_alloc(&g->G, (int64_t)(m + 1) * (m + 1));
   if (st == KRY_OK) st = dev_alloc(&g->beta, 1);
   if (st == KRY_OK) st = dev_alloc(&g->y, m);
   if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 2 * m);
@@ -728,6 +730,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   }
   hipStream_t s = ctx->stream;
   (void)hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(m + 1) * m, s);
+  (void)hipMemsetAsync(g->G, 0, sizeof(double) * (size_t)(m + 1) * (m + 1), s);
   (void)hipMemsetAsync(g->V, 0, sizeof(double) * (size_t)(m + 1) * g->ld, s);
   (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
   (void)hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)g->ld, s);
@@ -755,7 +758,7 @@ void kry_gmres_destroy(kry_gmres *g) {
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
                     g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
-                    g->dd, g->ud, g->R};
+                    g->dd, g->ud, g->R, g->G};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
   if (g->ext_h) (void)hipHostFree(g->ext_h);
@@ -898,25 +901,25 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   }
   const double *pin = part[0];
   int npin = np[0];
-  KCHK(finish_parts(g, &pin, kp + kp * (kp - 1) / 2, &npin));
+  KCHK(finish_parts(g, &pin, 2 * kp - 1, &npin));
   int cur = 1;
   for (int cs = kp; cs < nv; cs += K, cur++) {
     const int kc = nv - cs < K ? nv - cs : K;
     {
       ScopedKernelTimer t(g->ctx, (kp == K && kc == K) ? KRY_K_MGS : KRY_K_MGS_PART);
       launch_mgs_block(st, kp, kc, g->w, basis(g, ps), basis(g, cs), g->ld, pin, npin, part[cur & 1],
-                       &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n);
+                       &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n, g->G, g->m + 1, ps);
     }
     pin = part[cur & 1];
     npin = np[cur & 1];
-    KCHK(finish_parts(g, &pin, kc + kc * (kc - 1) / 2, &npin));
+    KCHK(finish_parts(g, &pin, 2 * kc - 1, &npin));
     ps = cs;
     kp = kc;
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
     launch_mgs_block(st, kp, 0, g->w, basis(g, ps), nullptr, g->ld, pin, npin, part[cur & 1], &np[cur & 1],
-                     g->H + (int64_t)ps * g->m + j, g->m, n);
+                     g->H + (int64_t)ps * g->m + j, g->m, n, g->G, g->m + 1, ps);
   }
   pin = part[cur & 1];
   npin = np[cur & 1];

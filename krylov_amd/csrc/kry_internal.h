@@ -13,8 +13,8 @@ constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups
 constexpr int kMaxParts = 2048;    // partial sums per reduction buffer
 constexpr int kMaxM = 256;         // largest Krylov dimension supported
-constexpr int kMgsBlock = 8;       // most Gram-Schmidt links fused into one sweep over w
-constexpr int kMaxRed = kMgsBlock + kMgsBlock * (kMgsBlock - 1) / 2;  // partial-sum arrays per pass
+constexpr int kMgsBlock = 16;      // most Gram-Schmidt links fused into one sweep over w
+constexpr int kMaxRed = 2 * kMgsBlock - 1;  // partial-sum arrays per pass: dots + Gram column of the last vector
 
 // Five coefficient bands of a stencil operator on a rows x cols padded grid.
 struct Bands {
@@ -56,7 +56,7 @@ void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, 
 void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
                        int nparts, int64_t n, double *out);
 
-// y = A x; with kc > 0 also the partial sums of <y, c_k> and <c_a, c_b> for the
+// y = A x; with kc > 0 also the partial sums of <y, c_k> and <c_a, c_{kc-1}> for the
 // kc vectors cbase + k*ld (layout: part[q * nparts + workgroup], dots first)
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                          double *y, int kc, const double *cbase, int64_t ld, double *part,
@@ -68,12 +68,15 @@ void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, 
                      double *part, int *nparts);
 
 // One blocked Gram-Schmidt sweep: finish the kp coefficients of the previous
-// group (pbase, pbase+ld, ...) from part_in, store them at hout[k*hstride],
-// apply them to w, and accumulate the dots / Gram entries of the next kc
-// vectors (cbase, cbase+ld, ...) into part_out; kc == 0: <w, w> instead.
+// group (pbase, pbase+ld, ...; basis vectors gp .. gp+kp-1) from part_in and the
+// carried Gram matrix G (row-major, leading dimension gld; the group's new
+// column is stored there), store them at hout[k*hstride], apply them to w, and
+// accumulate the dots / last-vector Gram entries of the next kc <= kp vectors
+// (cbase, cbase+ld, ...) into part_out; kc == 0: <w, w> instead.
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
-                      double *part_out, int *np_out, double *hout, int hstride, int64_t n);
+                      double *part_out, int *np_out, double *hout, int hstride, int64_t n, double *G,
+                      int gld, int gp);
 
 // y = argmin ||beta e1 - H y|| through the normal equations and an un-pivoted
 // Doolittle LU, in the reference's loop order.  work: 3*m*m + 2*m doubles.

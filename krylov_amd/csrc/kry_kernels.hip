@@ -76,7 +76,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ d2 ld_nt(const d2 *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_nt(d2 v, d2 *p) { __builtin_nontemporal_store(v, p); }
 
-constexpr int nred(int k) { return k + k * (k - 1) / 2; }
+// partial-sum arrays of a group of k vectors: k dot products with the work vector and the
+// k - 1 Gram entries <c_a, c_{k-1}> of the group's last vector
+constexpr int nred(int k) { return k > 0 ? 2 * k - 1 : 0; }
 
 // Totals of NQ partial-sum arrays, evaluated by the same expression tree in
 // every workgroup: wave q % 4 reduces array q with its 64 lanes.
@@ -200,19 +202,25 @@ __global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict_
 // The reference orthogonalises w against v_0, v_1, ... one vector at a time:
 //   h_i = <w, v_i>;  w -= h_i v_i        (dot taken with the UPDATED w).
 // Every link is one sweep over w.  This kernel does up to kMgsBlock links per
-// sweep.  For a group c_0..c_{KC-1} of basis vectors it accumulates, in one
+// sweep.  Basis vectors are taken in fixed groups of K (group g = vectors
+// g K .. g K + K - 1).  For a group c_0..c_{KC-1} the kernel accumulates, in one
 // pass over the already-updated w,
-//     d_k  = <w, c_k>            and      g_ab = <c_a, c_b>   (a < b),
-// and the NEXT kernel (its prologue, identically in every workgroup) recovers
-// the modified-Gram-Schmidt coefficients exactly as the recurrence defines them,
+//     d_k  = <w, c_k>            and      g_a = <c_a, c_{KC-1}>   (a < KC-1),
+// i.e. the Gram entries of the group's LAST vector only: the Gram entries of
+// the earlier vectors were produced the same way in the Arnoldi step in which
+// each of them was the newest vector, and are kept in the small matrix G.  The
+// NEXT kernel (its prologue, identically in every workgroup) recovers the
+// modified-Gram-Schmidt coefficients exactly as the recurrence defines them,
 //     h_0 = d_0,  h_1 = d_1 - h_0 g_01,  h_2 = d_2 - h_0 g_02 - h_1 g_12, ...
-// (because <w - h_0 c_0, c_1> = <w, c_1> - h_0 <c_0, c_1>), then applies
+// (because <w - h_0 c_0, c_1> = <w, c_1> - h_0 <c_0, c_1>), stores the new Gram
+// column in G, then applies
 //     w -= h_0 c_0;  w -= h_1 c_1; ...   element-wise in the reference's order
 // (multiply, then subtract) while taking the dots of the following group.
 // KC = 0 with NORM: the last pass of an Arnoldi step, accumulates <w, w>.
 //
-// Partial sums: part[q * gridDim.x + workgroup], q < KC + KC (KC-1)/2 (dots
-// first, then Gram entries in (a, b) lexicographic order), or q = 0 for NORM.
+// Partial sums: part[q * gridDim.x + workgroup], q < 2 KC - 1 (dots first, then
+// the Gram entries of the last vector), or q = 0 for NORM.
+// G: row-major, leading dimension gld; the previous group starts at row/column gp.
 // ---------------------------------------------------------------------------
 template <int KP, int KC, bool NORM, int U>
 __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
@@ -221,34 +229,36 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
                                                        const double *__restrict__ part_in, int np_in,
                                                        double *__restrict__ part_out,
                                                        double *__restrict__ hout, int hstride,
-                                                       int64_t n, const int *__restrict__ stop) {
+                                                       int64_t n, double *__restrict__ G, int gld, int gp,
+                                                       const int *__restrict__ stop) {
   if (stopped(stop)) return;
   constexpr int NQI = nred(KP);
   constexpr int NQO = NORM ? 1 : nred(KC);
   __shared__ double tot[NQI];
+  __shared__ double gs[KP * KP];
   __shared__ double red[NQO * (kBlock / 64)];
-  sum_parts_multi<NQI>(part_in, np_in, tot);
+  // Gram entries of the previous group's earlier vectors (upper triangle, a < k < KP-1)
+  for (int t = threadIdx.x; t < KP * KP; t += kBlock) {
+    const int a = t / KP, k = t % KP;
+    gs[t] = (a < k && k < KP - 1) ? G[(size_t)(gp + a) * gld + (gp + k)] : 0.0;
+  }
+  sum_parts_multi<NQI>(part_in, np_in, tot);  // ends with a barrier
   // modified Gram-Schmidt coefficients of the previous group
   double h[KP];
-  {
-    int gq = KP;  // Gram entries follow the KP dots, (a, b) lexicographic
-    double g[KP > 1 ? KP * KP : 1];
 #pragma unroll
-    for (int a = 0; a < KP; a++)
+  for (int k = 0; k < KP; k++) {
+    double v = tot[k];
 #pragma unroll
-      for (int b = a + 1; b < KP; b++) g[a * KP + b] = tot[gq++];
-#pragma unroll
-    for (int k = 0; k < KP; k++) {
-      double v = tot[k];
-#pragma unroll
-      for (int a = 0; a < k; a++) v = v - h[a] * g[a * KP + k];
-      h[k] = v;
-    }
+    for (int a = 0; a < k; a++) v = v - h[a] * (k == KP - 1 ? tot[KP + a] : gs[a * KP + k]);
+    h[k] = v;
   }
   if (blockIdx.x == 0 && threadIdx.x < KP) {
 #pragma unroll
     for (int k = 0; k < KP; k++)
-      if ((int)threadIdx.x == k) hout[(size_t)k * hstride] = h[k];
+      if ((int)threadIdx.x == k) {
+        hout[(size_t)k * hstride] = h[k];
+        if (k < KP - 1) G[(size_t)(gp + k) * gld + (gp + KP - 1)] = tot[KP + k];  // new Gram column
+      }
   }
   const int64_t n2 = n >> 1;
   d2 *w2 = reinterpret_cast<d2 *>(w);
@@ -281,16 +291,13 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
           acc[0] = fma(r.x, r.x, acc[0]);
           acc[0] = fma(r.y, r.y, acc[0]);
         } else {
-          int q = KC;
 #pragma unroll
           for (int a = 0; a < KC; a++) {
             acc[a] = fma(r.x, cv[a][u].x, acc[a]);
             acc[a] = fma(r.y, cv[a][u].y, acc[a]);
-#pragma unroll
-            for (int b = a + 1; b < KC; b++) {
-              acc[q] = fma(cv[a][u].x, cv[b][u].x, acc[q]);
-              acc[q] = fma(cv[a][u].y, cv[b][u].y, acc[q]);
-              q++;
+            if (a < KC - 1) {
+              acc[KC + a] = fma(cv[a][u].x, cv[KC - 1][u].x, acc[KC + a]);
+              acc[KC + a] = fma(cv[a][u].y, cv[KC - 1][u].y, acc[KC + a]);
             }
           }
         }
@@ -306,15 +313,11 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
     if (NORM) {
       acc[0] = fma(r, r, acc[0]);
     } else {
-      int q = KC;
 #pragma unroll
       for (int a = 0; a < KC; a++) {
         acc[a] = fma(r, cbase[(int64_t)a * ld + e], acc[a]);
-#pragma unroll
-        for (int b = a + 1; b < KC; b++) {
-          acc[q] = fma(cbase[(int64_t)a * ld + e], cbase[(int64_t)b * ld + e], acc[q]);
-          q++;
-        }
+        if (a < KC - 1)
+          acc[KC + a] = fma(cbase[(int64_t)a * ld + e], cbase[(int64_t)(KC - 1) * ld + e], acc[KC + a]);
       }
     }
   }
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(64) void k_ext_solve(const double *__restrict__ R, 
 // Operator application (include/matrix.hpp:23-33 for a 5-band / CSR matrix),
 // fused with the first Gram-Schmidt group: besides y = A x the kernels
 // accumulate <y, c_k> for KC basis vectors c_k = cbase + k*ld and the Gram
-// entries <c_a, c_b> (layout of the partial sums as in k_mgs_block).
+// entries <c_a, c_{KC-1}> of the last one (partial sums laid out as in k_mgs_block).
 // ---------------------------------------------------------------------------
 template <int KC>
 __device__ __forceinline__ void accum_scalar(double r, const double *__restrict__ cbase, int64_t ld,
@@ -497,14 +500,11 @@ __device__ __forceinline__ void accum_scalar(double r, const double *__restrict_
   double c[KC > 0 ? KC : 1];
 #pragma unroll
   for (int a = 0; a < KC; a++) c[a] = cbase[(int64_t)a * ld + k];
-  int q = KC;
+  if constexpr (KC > 0) {
 #pragma unroll
-  for (int a = 0; a < KC; a++) {
-    acc[a] = fma(r, c[a], acc[a]);
-#pragma unroll
-    for (int b = a + 1; b < KC; b++) {
-      acc[q] = fma(c[a], c[b], acc[q]);
-      q++;
+    for (int a = 0; a < KC; a++) {
+      acc[a] = fma(r, c[a], acc[a]);
+      if (a < KC - 1) acc[KC + a] = fma(c[a], c[KC - 1], acc[KC + a]);
     }
   }
 }
@@ -601,16 +601,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
         d2 r = {r0, r1};
         st_nt(r, &y2[i]);
         if (KC > 0) {
-          int q = KC;
 #pragma unroll
           for (int a = 0; a < KC; a++) {
             acc[a] = fma(r0, cv[a].x, acc[a]);
             acc[a] = fma(r1, cv[a].y, acc[a]);
-#pragma unroll
-            for (int c2 = a + 1; c2 < KC; c2++) {
-              acc[q] = fma(cv[a].x, cv[c2].x, acc[q]);
-              acc[q] = fma(cv[a].y, cv[c2].y, acc[q]);
-              q++;
+            if (a < KC - 1) {
+              acc[KC + a] = fma(cv[a].x, cv[KC - 1].x, acc[KC + a]);
+              acc[KC + a] = fma(cv[a].y, cv[KC - 1].y, acc[KC + a]);
             }
           }
         }
@@ -1320,9 +1317,10 @@ int sweep_grid(int64_t n2, int streams, int unroll) {
   if (g >= 256) {
     g = g / 256 * 256;  // whole waves of workgroups over the 256 CUs: no CU gets an extra one
     if (g > 1024) g = 1024;
-  } else {
+  } else if (streams <= 18) {
     g = g / 8 * 8;  // fewer workgroups than CUs: all resident at once, spread evenly over the 8 XCDs
-    if (g < 64) g = 64;
+  } else {
+    g = 256;  // very wide sweeps (measured with 34 streams): one workgroup per CU beats fewer
   }
   const int64_t tiles = (n2 + (int64_t)kBlock * unroll - 1) / ((int64_t)kBlock * unroll);
   if (g > tiles) g = tiles;
@@ -1435,57 +1433,69 @@ void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, 
   SpmvCsrKc<>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts);
 }
 
+struct MgsArgs {
+  double *w;
+  const double *pbase, *cbase;
+  int64_t ld;
+  const double *part_in;
+  int np_in;
+  double *part_out;
+  int *np_out;
+  double *hout;
+  int hstride;
+  int64_t n;
+  double *G;
+  int gld, gp;
+};
+
 template <int KP, int KC, bool NORM>
-static void launch_mgs_block_t(hipStream_t st, double *w, const double *pbase, const double *cbase,
-                               int64_t ld, const double *part_in, int np_in, double *part_out,
-                               int *np_out, double *hout, int hstride, int64_t n) {
+static void launch_mgs_block_t(hipStream_t st, const MgsArgs &a) {
   constexpr int streams = 2 + KP + KC;
   constexpr int U = sweep_unroll(streams);
-  const int g = sweep_grid(n >> 1, streams, U);
-  *np_out = g;
-  hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, U>), dim3(g), dim3(kBlock), 0, st, w, pbase, cbase, ld,
-                     part_in, np_in, part_out, hout, hstride, n, t_stop);
+  const int g = sweep_grid(a.n >> 1, streams, U);
+  *a.np_out = g;
+  hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, U>), dim3(g), dim3(kBlock), 0, st, a.w, a.pbase, a.cbase, a.ld,
+                     a.part_in, a.np_in, a.part_out, a.hout, a.hstride, a.n, a.G, a.gld, a.gp, t_stop);
 }
 
-// (kp, kc) -> template arguments (kp 1..kMgsBlock, kc 0..kMgsBlock; kc == 0 is the norm pass)
-template <int KP, int KC = kMgsBlock>
+// (kp, kc) -> template arguments.  Groups are aligned, so a sweep either joins two
+// full groups (kp = kc = K for the block size K in use), or its second group is the
+// step's last, shorter one (kc < kp = K), or it is the closing pass (kc = 0): only
+// kc <= kp is instantiated.
+template <int KP, int KC = KP>
 struct MgsKc {
-  static void go(hipStream_t st, int kc, double *w, const double *pbase, const double *cbase, int64_t ld,
-                 const double *part_in, int np_in, double *part_out, int *np_out, double *hout, int hstride,
-                 int64_t n) {
+  static void go(hipStream_t st, int kc, const MgsArgs &a) {
     if (kc == KC)
-      launch_mgs_block_t<KP, KC, KC == 0>(st, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+      launch_mgs_block_t<KP, KC, KC == 0>(st, a);
     else
-      MgsKc<KP, KC - 1>::go(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+      MgsKc<KP, KC - 1>::go(st, kc, a);
   }
 };
 template <int KP>
 struct MgsKc<KP, -1> {
-  static void go(hipStream_t, int, double *, const double *, const double *, int64_t, const double *, int, double *,
-                 int *, double *, int, int64_t) {}
+  static void go(hipStream_t, int, const MgsArgs &) {}
 };
 
 template <int KP = kMgsBlock>
 struct MgsKp {
-  static void go(hipStream_t st, int kp, int kc, double *w, const double *pbase, const double *cbase, int64_t ld,
-                 const double *part_in, int np_in, double *part_out, int *np_out, double *hout, int hstride,
-                 int64_t n) {
+  static void go(hipStream_t st, int kp, int kc, const MgsArgs &a) {
     if (kp == KP)
-      MgsKc<KP>::go(st, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+      MgsKc<KP>::go(st, kc, a);
     else
-      MgsKp<KP - 1>::go(st, kp, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+      MgsKp<KP - 1>::go(st, kp, kc, a);
   }
 };
 template <>
 struct MgsKp<0> {
-  static void go(hipStream_t, int, int, double *, const double *, const double *, int64_t, const double *, int,
-                 double *, int *, double *, int, int64_t) {}
+  static void go(hipStream_t, int, int, const MgsArgs &) {}
 };
 
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
-                      double *part_out, int *np_out, double *hout, int hstride, int64_t n) {
-  MgsKp<>::go(st, kp, kc, w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n);
+                      double *part_out, int *np_out, double *hout, int hstride, int64_t n, double *G,
+                      int gld, int gp) {
+  const MgsArgs a{w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n, G, gld, gp};
+  MgsKp<>::go(st, kp, kc, a);
 }
 
 void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,
