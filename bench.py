@@ -13,8 +13,8 @@ N > 1 the same mesh is split into row blocks, one rank per GPU (strong
 scaling), with halo exchange and all-reduced dot products over RCCL.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel (one full Gram-Schmidt sweep, 80 B per
-                 unknown) timed live with HIP events on the stream it runs on;
+  roofline     : the dominant kernel family (largest share of the step) timed
+                 live with HIP events on the stream it runs on;
   cpu_baseline : the single-threaded CPU restatement (oracle/) timed on this
                  box's host cores on a bounded sample of the same workload.
 """
@@ -183,29 +183,39 @@ def main():
                          "alg_bytes_per_launch": per_launch,
                          "gbps": round(per_launch / (avg_ms * 1e-3) / 1e9, 1) if per_launch else None}
     roofline = None
+    # The dominant kernel: the kernel family (one template, launched with varying numbers of
+    # basis vectors as the Krylov space grows) with the largest share of the timed region.
+    # achieved = algorithmic bytes of the family's launches in one cycle / their number,
+    # divided by the mean launch duration measured with HIP events.
     # (a monitored solve also launches kernels that return at once after convergence:
-    #  their per-class averages do not describe the sweep, so no roofline entry there)
-    if "mgs_block_full" in kernels and not ext_stats:
-        k = kernels["mgs_block_full"]
-        # one full Gram-Schmidt sweep: w read + written, K basis vectors applied,
-        # K basis vectors dotted: (2 + 2 K) x 8 B per unknown
+    #  their averages do not describe the kernel, so no roofline entry there)
+    families = {
+        "spmv_dots": "k_spmv_stencil_v2<kc> (operator apply fused with the dot products of the first kc <= %d basis vectors)",
+        "mgs_block_full": "k_mgs_block<%d,%d> (Gram-Schmidt sweep: %d projections applied + %d dots)",
+        "mgs_block_part": "k_mgs_block<%d,kc> (Gram-Schmidt sweep: %d projections applied + kc < %d dots)",
+        "mgs_last": "k_mgs_block<kp,0> (closing Gram-Schmidt sweep of an Arnoldi step: kp <= %d projections applied + norm)",
+    }
+    timed = {n: k for n, k in kernels.items() if n in families and k["gbps"]}
+    if timed and not ext_stats:
         K = dev.solver().get_mgs_block()
-        per_launch = (2.0 + 2.0 * K) * 8.0 * N
-        achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
+        name = max(timed, key=lambda n: timed[n]["total_ms"])
+        k = timed[name]
+        label = families[name] % ((K,) * families[name].count("%d"))
+        achieved = k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("mesh") == n_side and tj.get("mgs_block") == K:
-                    traffic = tj.get("mgs_block_full_hbm_bytes_per_launch")
+                if tj.get("mesh") == n_side and tj.get("m") == m and tj.get("mgs_block") == K:
+                    traffic = tj.get("hbm_bytes_per_launch", {}).get(name)
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_mgs_block<%d,%d,false,1> (Gram-Schmidt sweep: %d projections applied + %d dots, "
-                              "%d B per unknown)" % (K, K, K, K, 16 + 16 * K),
+        roofline = {"bound": "hbm", "kernel": label, "kernel_class": name,
+                    "share_of_kernel_time": round(k["total_ms"] / sum(v["total_ms"] for v in kernels.values()), 4),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "alg_bytes_per_launch": per_launch, "avg_launch_ms": k["avg_ms"],
+                    "alg_bytes_per_launch": k["alg_bytes_per_launch"], "avg_launch_ms": k["avg_ms"],
                     "launches_timed": k["launches"]}
     total_alg = sum(bytes_cycle) * args.steps
     out = {
@@ -222,6 +232,7 @@ def main():
                                   (" + line preconditioner" + (" (applied to the result)" if args.fixed_precond else ""))
                                   if args.tdp else ""),
                    "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
+                   "mgs_block": dev.solver().get_mgs_block(),
                    "parallelism": "1 GPU", "graph": bool(args.graph),
                    "solver_mode": ("restarted, residual-monitored, rtol %g" % args.extended) if args.extended > 0.0
                    else "reference: one fixed cycle of m steps"},

@@ -171,7 +171,7 @@ int kry_gmres_prev_result(kry_gmres *g, double *out_host);
 /* Device pointer to the n-entry result vector. */
 const double *kry_gmres_result_device(kry_gmres *g);
 /* Number of modified-Gram-Schmidt links fused into one sweep over the work
- * vector, 1..16 (default 16).  1 is the reference's plain chain, one link per
+ * vector: 1, 2, 3, 4, 8, 16 or 32 (default 32).  1 is the reference's plain chain, one link per
  * sweep (include/solver.hpp:198-207); larger groups take the group's dot
  * products in one pass and recover the same coefficients through the group's
  * Gram entries, h_k = <w, v_k> - sum_{a<k} h_a <v_a, v_k>, which are computed

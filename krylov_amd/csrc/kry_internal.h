@@ -13,7 +13,7 @@ constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups
 constexpr int kMaxParts = 2048;    // partial sums per reduction buffer
 constexpr int kMaxM = 256;         // largest Krylov dimension supported
-constexpr int kMgsBlock = 16;      // most Gram-Schmidt links fused into one sweep over w
+constexpr int kMgsBlock = 32;      // most Gram-Schmidt links fused into one sweep over w
 constexpr int kMaxRed = 2 * kMgsBlock - 1;  // partial-sum arrays per pass: dots + Gram column of the last vector
 
 // Five coefficient bands of a stencil operator on a rows x cols padded grid.
@@ -73,6 +73,8 @@ void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, 
 // column is stored there), store them at hout[k*hstride], apply them to w, and
 // accumulate the dots / last-vector Gram entries of the next kc <= kp vectors
 // (cbase, cbase+ld, ...) into part_out; kc == 0: <w, w> instead.
+// block sizes (links per sweep) for which sweep kernels exist
+bool mgs_block_supported(int k);
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
                       double *part_out, int *np_out, double *hout, int hstride, int64_t n, double *G,

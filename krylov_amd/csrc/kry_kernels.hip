@@ -1460,42 +1460,58 @@ static void launch_mgs_block_t(hipStream_t st, const MgsArgs &a) {
 
 // (kp, kc) -> template arguments.  Groups are aligned, so a sweep either joins two
 // full groups (kp = kc = K for the block size K in use), or its second group is the
-// step's last, shorter one (kc < kp = K), or it is the closing pass (kc = 0): only
-// kc <= kp is instantiated.
+// step's last, shorter one (0 < kc < kp = K), or it is the closing pass of a step
+// (kc = 0, any kp <= K).  Only those combinations are instantiated, for the block
+// sizes listed in mgs_block_supported().
 template <int KP, int KC = KP>
 struct MgsKc {
   static void go(hipStream_t st, int kc, const MgsArgs &a) {
     if (kc == KC)
-      launch_mgs_block_t<KP, KC, KC == 0>(st, a);
+      launch_mgs_block_t<KP, KC, false>(st, a);
     else
       MgsKc<KP, KC - 1>::go(st, kc, a);
   }
 };
 template <int KP>
-struct MgsKc<KP, -1> {
+struct MgsKc<KP, 0> {
   static void go(hipStream_t, int, const MgsArgs &) {}
 };
 
 template <int KP = kMgsBlock>
-struct MgsKp {
-  static void go(hipStream_t st, int kp, int kc, const MgsArgs &a) {
+struct MgsClosing {
+  static void go(hipStream_t st, int kp, const MgsArgs &a) {
     if (kp == KP)
-      MgsKc<KP>::go(st, kc, a);
+      launch_mgs_block_t<KP, 0, true>(st, a);
     else
-      MgsKp<KP - 1>::go(st, kp, kc, a);
+      MgsClosing<KP - 1>::go(st, kp, a);
   }
 };
 template <>
-struct MgsKp<0> {
-  static void go(hipStream_t, int, int, const MgsArgs &) {}
+struct MgsClosing<0> {
+  static void go(hipStream_t, int, const MgsArgs &) {}
 };
+
+bool mgs_block_supported(int k) { return k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16 || k == 32; }
 
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
                       double *part_out, int *np_out, double *hout, int hstride, int64_t n, double *G,
                       int gld, int gp) {
   const MgsArgs a{w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n, G, gld, gp};
-  MgsKp<>::go(st, kp, kc, a);
+  if (kc == 0) {
+    MgsClosing<>::go(st, kp, a);
+    return;
+  }
+  switch (kp) {
+    case 1: MgsKc<1>::go(st, kc, a); break;
+    case 2: MgsKc<2>::go(st, kc, a); break;
+    case 3: MgsKc<3>::go(st, kc, a); break;
+    case 4: MgsKc<4>::go(st, kc, a); break;
+    case 8: MgsKc<8>::go(st, kc, a); break;
+    case 16: MgsKc<16>::go(st, kc, a); break;
+    case 32: MgsKc<32>::go(st, kc, a); break;
+    default: break;  // excluded by mgs_block_supported() at the API
+  }
 }
 
 void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,

@@ -16,7 +16,7 @@ def rel(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("block", [1, 4, 8, 16])
+@pytest.mark.parametrize("block", [1, 4, 8, 16, 32])
 @pytest.mark.parametrize("name,args,m,tdp,rtol", [
     ("prob1", (38, 18), 10, False, 1e-12),
     ("prob1", (38, 18), 30, False, 1e-12),

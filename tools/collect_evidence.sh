@@ -15,3 +15,4 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_write.err
 python3 $ROOT/tools/parse_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.json
 find $OUT -name "*.csv" | head -20
+python3 $ROOT/tools/make_traffic.py $OUT > $OUT/traffic.json

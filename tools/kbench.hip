@@ -365,6 +365,15 @@ int main(int argc, char **argv) {
   // vectors with leading dimension ld for the K+K sweeps
   double *big; const long ld = (n + 31) / 32 * 32;
   CHECK(hipMalloc((void **)&big, sizeof(double) * ld * 17)); CHECK(hipMemset(big, 0, sizeof(double) * ld * 17));
+  if (argc > 2 && !strcmp(argv[2], "wide32")) {
+    double *big3; CHECK(hipMalloc((void **)&big3, sizeof(double) * ld * 65)); CHECK(hipMemset(big3, 0, sizeof(double) * ld * 65));
+    for (int G : {128, 256, 512}) {
+      snprintf(nm, sizeof nm, "VD 16+16 dots only U1 G%d (272 B)", G); run(nm, 272, [&](int r) { hipLaunchKernelGGL((vd<256, 1, 16>), dim3(G), dim3(256), 0, 0, big3, big3 + ld, big3 + 33 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VD 24+24 dots only U1 G%d (400 B)", G); run(nm, 400, [&](int r) { hipLaunchKernelGGL((vd<256, 1, 24>), dim3(G), dim3(256), 0, 0, big3, big3 + ld, big3 + 33 * ld, ld, part, n2); });
+      snprintf(nm, sizeof nm, "VD 32+32 dots only U1 G%d (528 B)", G); run(nm, 528, [&](int r) { hipLaunchKernelGGL((vd<256, 1, 32>), dim3(G), dim3(256), 0, 0, big3, big3 + ld, big3 + 33 * ld, ld, part, n2); });
+    }
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "wide16")) {
     double *big2; CHECK(hipMalloc((void **)&big2, sizeof(double) * ld * 33)); CHECK(hipMemset(big2, 0, sizeof(double) * ld * 33));
     for (int G : {96, 112, 120, 128, 192, 256}) {

@@ -3,7 +3,7 @@
 set -e
 for cfg in "8192 50 3" "2896 50 5" "2048 30 10" "1024 30 10"; do
   set -- $cfg
-  for k in 4 8 16; do
+  for k in 8 16 32; do
     KRY_MGS_BLOCK=$k timeout -k 10 300 python bench.py --mesh $1 --gmres-m $2 --steps $3 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/blk_$1_$k.json
     python - <<PY
 import json
