@@ -715,19 +715,24 @@ __global__ __launch_bounds__(kBlock) void k_small_solve(const double *__restrict
 // Device form: one wavefront owns LPW lines.  A chunk of kTdpC = 64 columns of
 // those lines is fetched with lane = column (each load instruction moves one
 // line's 512 contiguous bytes), parked in LDS, and then lane l < LPW walks
-// line l through the chunk out of LDS (row pitch 65 doubles: conflict-free in
-// both directions).  The next chunk's loads are issued before the walk and land
-// in registers while the dependent chain (one multiply-subtract and one true
-// division per element) runs, results go back through LDS so that the stores
-// are coalesced again.  The chain is latency-bound, so idle lanes cost
-// nothing and LPW is chosen for enough wavefronts to cover the memory
-// latency, not to fill lanes.
+// line l through the chunk out of LDS (row pitch 66 doubles: conflict-free in
+// both directions, two elements per LDS instruction in the walk).  The next
+// chunk's loads are issued before the walk and land in registers while the
+// dependent chain (one multiply-subtract and one true division per element)
+// runs; results go back through LDS so that the stores are coalesced again,
+// one chunk late so that they are older than the loads the next round waits
+// for.  LPW is chosen for enough wavefronts to cover the memory latency, not
+// to fill lanes.
 // ---------------------------------------------------------------------------
 constexpr int kTdpC = 64;
 
+// Row pitch 66 doubles: rows stay 16-byte aligned, so the walking lanes can move two
+// elements per LDS instruction, and 16 lanes x 4 dwords at a lane stride of 132 dwords
+// cover the 64 banks exactly once (no conflicts); the staging accesses (lane = column)
+// are consecutive in any case.
 template <int LPW>
-struct TdpTile {
-  double v[LPW][kTdpC + 1];
+struct alignas(16) TdpTile {
+  double v[LPW][kTdpC + 2];
 };
 
 template <int LPW>
@@ -758,14 +763,23 @@ constexpr int kTdpB = 8;
 
 template <int LPW>
 __device__ __forceinline__ void tdp_ld_block(double (&r)[kTdpB], const TdpTile<LPW> &t, int lane, int j0) {
+  const d2 *p = reinterpret_cast<const d2 *>(&t.v[lane][j0]);  // j0 is a multiple of kTdpB (even)
 #pragma unroll
-  for (int k = 0; k < kTdpB; k++) r[k] = t.v[lane][j0 + k];
+  for (int k = 0; k < kTdpB / 2; k++) {
+    const d2 x = p[k];
+    r[2 * k] = x.x;
+    r[2 * k + 1] = x.y;
+  }
 }
 
 template <int LPW>
 __device__ __forceinline__ void tdp_st_block(TdpTile<LPW> &t, const double (&r)[kTdpB], int lane, int j0) {
+  d2 *p = reinterpret_cast<d2 *>(&t.v[lane][j0]);
 #pragma unroll
-  for (int k = 0; k < kTdpB; k++) t.v[lane][j0 + k] = r[k];
+  for (int k = 0; k < kTdpB / 2; k++) {
+    d2 x = {r[2 * k], r[2 * k + 1]};
+    p[k] = x;
+  }
 }
 
 // forward elimination over one chunk: y_j = (s_j - y_{j-1} lo_j) / dd_j
@@ -896,7 +910,11 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ 
                                                       int64_t nlines, int64_t L,
                                                       const int *__restrict__ stop) {
   if (stopped(stop)) return;
-  __shared__ TdpTile<LPW> ts, ta, td;
+  // The running right-hand side has two tiles: chunk c is walked in one while chunk c-1
+  // leaves the other.  Its stores are issued before the loads of chunk c+1, so the wait
+  // for those loads at the top of the next round (the memory counter retires in order)
+  // never stalls on stores that were issued after them.
+  __shared__ TdpTile<LPW> ts[2], ta, td;
   const int lane = threadIdx.x;
   const int64_t line0 = (int64_t)blockIdx.x * LPW;
   const int nl = (int)((nlines - line0) < LPW ? (nlines - line0) : LPW);
@@ -913,10 +931,12 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ 
   double prev = 0.0;
   for (int64_t c = 0; c < nchunk; c++) {
     const int64_t col = c * kTdpC + lane;
-    tdp_park<LPW>(ts, rs, lane);
+    TdpTile<LPW> &cur = ts[c & 1];
+    tdp_park<LPW>(cur, rs, lane);
     tdp_park<LPW>(ta, ra, lane);
     tdp_park<LPW>(td, rd, lane);
     __syncthreads();
+    if (c > 0) tdp_flush<LPW>(ts[(c - 1) & 1], out, line0, nl, L, col - kTdpC, lane);
     if (c + 1 < nchunk) {
       tdp_fetch<LPW>(rs, sol, line0, nl, L, col + kTdpC, 0.0);
       tdp_fetch<LPW>(ra, lo, line0, nl, L, col + kTdpC, 0.0);
@@ -924,21 +944,22 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ 
     }
     if (lane < nl) {
       const int cw = (int)((L - c * kTdpC) < kTdpC ? (L - c * kTdpC) : kTdpC);
-      prev = tdp_walk_forward<LPW>(ts, ta, td, lane, cw, prev);
+      prev = tdp_walk_forward<LPW>(cur, ta, td, lane, cw, prev);
     }
     __syncthreads();
-    tdp_flush<LPW>(ts, out, line0, nl, L, col, lane);
-    __syncthreads();
   }
+  tdp_flush<LPW>(ts[(nchunk - 1) & 1], out, line0, nl, L, (nchunk - 1) * kTdpC + lane, lane);
   // back substitution: element L-1 keeps its forward value (= prev); walk the
-  // chunks in reverse
+  // chunks in reverse.  Every element of out is re-read by the thread that stored it.
   tdp_fetch<LPW>(rs, out, line0, nl, L, (nchunk - 1) * kTdpC + lane, 0.0);
   tdp_fetch<LPW>(ra, ud, line0, nl, L, (nchunk - 1) * kTdpC + lane, 0.0);
   for (int64_t c = nchunk - 1; c >= 0; c--) {
     const int64_t col = c * kTdpC + lane;
-    tdp_park<LPW>(ts, rs, lane);
+    TdpTile<LPW> &cur = ts[c & 1];
+    tdp_park<LPW>(cur, rs, lane);
     tdp_park<LPW>(ta, ra, lane);
     __syncthreads();
+    if (c + 1 < nchunk) tdp_flush<LPW>(ts[(c + 1) & 1], out, line0, nl, L, col + kTdpC, lane);
     if (c > 0) {
       tdp_fetch<LPW>(rs, out, line0, nl, L, col - kTdpC, 0.0);
       tdp_fetch<LPW>(ra, ud, line0, nl, L, col - kTdpC, 0.0);
@@ -947,12 +968,11 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ 
       const int cw = (int)((L - c * kTdpC) < kTdpC ? (L - c * kTdpC) : kTdpC);
       // the last chunk starts one element lower and therefore never takes the blocked walk
       const int jtop = (c == nchunk - 1) ? cw - 2 : cw - 1;
-      prev = tdp_walk_backward<LPW>(ts, ta, lane, jtop, prev);
+      prev = tdp_walk_backward<LPW>(cur, ta, lane, jtop, prev);
     }
     __syncthreads();
-    tdp_flush<LPW>(ts, out, line0, nl, L, col, lane);
-    __syncthreads();
   }
+  tdp_flush<LPW>(ts[0], out, line0, nl, L, lane, lane);
 }
 
 __global__ __launch_bounds__(kBlock) void k_tdp_extract_csr(const int64_t *__restrict__ rowptr,
