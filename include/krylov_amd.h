@@ -206,7 +206,8 @@ enum kry_kernel_class {
   KRY_K_PRECOND = 6,   /* tridiagonal line solves                               */
   KRY_K_ASSEMBLY = 7,  /* ghost fill, right-hand side, state update             */
   KRY_K_OTHER = 8,     /* reduced m x m solve                                   */
-  KRY_K_COUNT = 9
+  KRY_K_FUSED = 9,     /* one-sweep Arnoldi step: normalise, orthogonalise, apply A, dots */
+  KRY_K_COUNT = 10
 };
 int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY_K_COUNT],
                           int launches[KRY_K_COUNT]);

@@ -15,10 +15,10 @@ PKG = os.path.join(ROOT, "krylov_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkrylov_amd.so")
 
-HIP_SOURCES = ["kry_kernels.hip", "kry_api.hip"]
+HIP_SOURCES = ["kry_kernels.hip", "kry_fused.hip", "kry_api.hip"]
 # -ffp-contract=off: element-wise arithmetic must round like the reference's
 # scalar C++ (no fused multiply-add); reductions call fma() explicitly.
-HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
              "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -37,11 +37,28 @@ def hipcc():
 
 
 def build_lib(force=False, verbose=False):
+    """Compile every translation unit (in parallel, objects under csrc/_obj) and link the library."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "kry_internal.h"), os.path.join(ROOT, "include", "krylov_amd.h")]
-    if not force and _newer(LIB, deps):
+    hdrs = [os.path.join(CSRC, "kry_internal.h"), os.path.join(CSRC, "kry_device.h"),
+            os.path.join(ROOT, "include", "krylov_amd.h")]
+    if not force and _newer(LIB, srcs + hdrs):
         return LIB
-    cmd = [hipcc()] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB, "-ldl"]
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not force and _newer(obj, [src] + hdrs):
+            continue
+        cmd = [hipcc()] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

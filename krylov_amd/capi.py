@@ -18,9 +18,9 @@ OK = 0
 FIELD_T, FIELD_U, FIELD_V = 0, 1, 2
 BOTTOM, TOP, LEFT, RIGHT = 0, 1, 2, 3
 GMRES_PLAIN, GMRES_TDP, GMRES_FIXED_PRECOND, GMRES_EXTENDED = 0, 1, 2, 8
-K_SPMV, K_MGS, K_MGS_PART, K_MGS_LAST, K_NORMALIZE, K_COMBINE, K_PRECOND, K_ASSEMBLY, K_OTHER, K_COUNT = range(10)
+K_SPMV, K_MGS, K_MGS_PART, K_MGS_LAST, K_NORMALIZE, K_COMBINE, K_PRECOND, K_ASSEMBLY, K_OTHER, K_FUSED, K_COUNT = range(11)
 K_NAMES = ["spmv_dots", "mgs_block_full", "mgs_block_part", "mgs_last", "normalize", "combine", "precond", "assembly",
-           "small_solve"]
+           "small_solve", "arnoldi_fused"]
 
 # name -> (restype, argtypes); the list mirrors include/krylov_amd.h and is
 # checked against the header by the test-suite.

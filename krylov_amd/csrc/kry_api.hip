@@ -170,6 +170,9 @@ struct kry_op {
   int64_t nnz = 0;
   double *tx = nullptr, *ty = nullptr;  // staging for the host apply
   bool slab = false;  // local rows of a row-block decomposition
+  // bands s and n are zero where they would couple the two ends of a grid row
+  // (column 0 / the last column): the operator is a true 2-D stencil
+  bool wrap_free = false;
 };
 
 struct kry_gmres {
@@ -208,6 +211,13 @@ struct kry_gmres {
   double *R = nullptr;        // (m+1) x m rotated Hessenberg | cs (m) | sn (m) | gv (m+1)
   int last_iters = 0, last_cycles = 0, last_converged = 0;
   double last_relres = 0.0;
+  // one-sweep Arnoldi steps (plain mode, stencil operator, one rank): first step that
+  // uses them (< 0: never), the un-normalised new vector (ping-pong), the second
+  // operator-result buffer (the first is w), partial sums, totals, coefficients
+  int fused_from = -1;
+  double *fu[2] = {nullptr, nullptr};
+  double *fw = nullptr;
+  double *fparts = nullptr, *ftot = nullptr, *fcoef = nullptr;
 };
 
 struct kry_ie {
@@ -533,6 +543,9 @@ int kry_op_create_stencil(kry_ctx *ctx, int rows, int cols, const double *w, con
   op->cols = cols;
   op->n = (int64_t)rows * cols;
   op->own_bands = true;
+  op->wrap_free = true;
+  for (int r = 0; r < rows && op->wrap_free; r++)
+    if (s[(int64_t)r * cols] != 0.0 || n[(int64_t)r * cols + cols - 1] != 0.0) op->wrap_free = false;
   const double *src[5] = {w, s, c, n, e};
   for (int b = 0; b < 5; b++) {
     int st = dev_alloc(&op->band[b], op->n);
@@ -724,6 +737,21 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
     if (st == KRY_OK) st = dev_alloc(&g->ud, g->ld);
   }
+  if (st == KRY_OK && !(flags & (KRY_GMRES_EXTENDED | KRY_GMRES_TDP)) && ctx->nranks == 1 &&
+      m <= kFusedMaxM && m >= 3) {
+    int from = 8;
+    if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
+    if (from >= 0 && from > m - 2) from = m - 2;
+    if (from >= 0) {
+      st = dev_alloc(&g->fu[0], g->ld);
+      if (st == KRY_OK) st = dev_alloc(&g->fu[1], g->ld);
+      if (st == KRY_OK) st = dev_alloc(&g->fw, g->ld);
+      if (st == KRY_OK) st = dev_alloc(&g->fparts, (int64_t)kFusedRed * kMaxParts);
+      if (st == KRY_OK) st = dev_alloc(&g->ftot, kFusedRed);
+      if (st == KRY_OK) st = dev_alloc(&g->fcoef, kFusedCoef);
+      if (st == KRY_OK) g->fused_from = from;
+    }
+  }
   if (st != KRY_OK) {
     kry_gmres_destroy(g);
     return st;
@@ -758,7 +786,7 @@ void kry_gmres_destroy(kry_gmres *g) {
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
                     g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
-                    g->dd, g->ud, g->R, g->G};
+                    g->dd, g->ud, g->R, g->G, g->fu[0], g->fu[1], g->fw, g->fparts, g->ftot, g->fcoef};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
   if (g->ext_h) (void)hipHostFree(g->ext_h);
@@ -1008,13 +1036,66 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
   return KRY_OK;
 }
 
+// The one-sweep steps need a true 2-D stencil on one rank and a grid that fits the
+// partial-sum buffers.
+static bool fused_usable(const kry_gmres *g, const kry_op *op) {
+  return g->fused_from >= 0 && op->kind == 0 && op->wrap_free && !op->slab && g->ctx->nranks == 1 &&
+         fused_parts(op->rows, op->cols) <= kMaxParts;
+}
+
+// Steps fused_from .. m-1 of a cycle, one sweep over the basis each (kry_fused.hip).
+// On entry the basis holds v_0..v_from; on return v_0..v_m and H are complete.
+static int fused_steps_async(kry_gmres *g, kry_op *op) {
+  hipStream_t st = g->ctx->stream;
+  const int m = g->m, i0 = g->fused_from;
+  const int64_t n = g->n;
+  const Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
+  double *tb[2] = {g->w, g->fw};
+  int np = 0;
+  {
+    // t = A v_from with the dots against v_0..v_from and the Gram column of v_from
+    ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
+    op_apply_async(op, basis(g, i0), tb[i0 & 1], i0 + 1, basis(g, 0), g->ld, g->fparts, &np, false);
+  }
+  launch_reduce_parts_wide(st, g->fparts, 2 * (i0 + 1) - 1, np, g->ftot);
+  for (int i = i0; i < m; i++) {
+    const bool boot = i == i0;
+    launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef);
+    const double *u_in = boot ? basis(g, i) : g->fu[i & 1];
+    double *v_out = boot ? nullptr : basis(g, i);
+    if (i < m - 1) {
+      {
+        ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out,
+                             g->fu[(i + 1) & 1], tb[(i + 1) & 1], g->fparts, &np);
+      }
+      launch_reduce_parts_wide(st, g->fparts, 2 * i + 4, np, g->ftot);
+    } else {
+      ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
+      launch_arnoldi_close(st, i, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out, g->fu[(i + 1) & 1], n,
+                           g->fparts, &np);
+    }
+  }
+  {
+    ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
+    launch_scale_from(st, g->fu[m & 1], basis(g, m), g->fparts, np, n, g->H + (int64_t)m * m + (m - 1));
+  }
+  g->nvec = m + 1;
+  return launch_ok("one-sweep Arnoldi steps");
+}
+
 static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_dev) {
   if (g->flags & KRY_GMRES_EXTENDED) return solve_extended(g, op, b_dev, x_dev);
   hipStream_t st = g->ctx->stream;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   KCHK(initial_subspace_async(g, b_dev));
   HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
-  for (int i = 0; i < g->m; i++) KCHK(arnoldi_async(g, op));
+  if (fused_usable(g, op)) {
+    for (int i = 0; i < g->fused_from; i++) KCHK(arnoldi_async(g, op));
+    KCHK(fused_steps_async(g, op));
+  } else {
+    for (int i = 0; i < g->m; i++) KCHK(arnoldi_async(g, op));
+  }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
     launch_small_solve(st, g->H, g->beta, g->m, g->y, g->work);
@@ -1166,7 +1247,9 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
   const int K = g->kblock;
   // bytes of the operator itself: five bands, or CSR values + indices + row pointers
   const double opb = op->kind == 0 ? 5.0 * N : 12.0 * (double)op->nnz + 8.0 * (double)(op->n + 1);
-  for (int j = 0; j < m; j++) {
+  const bool fused = fused_usable(g, op);
+  const int chain_steps = fused ? g->fused_from : m;
+  for (int j = 0; j < chain_steps; j++) {
     const int nv = j + 1;
     int kp = nv < K ? nv : K;
     bytes[KRY_K_SPMV] += opb + N + N + kp * N;  // operator, x read, y written, first group read
@@ -1181,8 +1264,21 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     bytes[KRY_K_MGS_LAST] += (2.0 + kp) * N;
     launches[KRY_K_MGS_LAST] += 1;
   }
-  bytes[KRY_K_NORMALIZE] = 2.0 * N * m + 3.0 * N;  // m normalisations + ||b|| and v_0 = b/||b||
-  launches[KRY_K_NORMALIZE] = m + 2;
+  if (fused) {
+    const int i0 = g->fused_from;
+    bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
+    launches[KRY_K_SPMV] += 1;
+    for (int i = i0; i < m - 1; i++) {
+      // read: t, u, v_0..v_{i-1}, operator; written: v_i (not in the first sweep), u, t
+      bytes[KRY_K_FUSED] += (2.0 + i) * N + opb + (i == i0 ? 2.0 : 3.0) * N;
+      launches[KRY_K_FUSED] += 1;
+    }
+    bytes[KRY_K_MGS_LAST] += (2.0 + (m - 1)) * N + 2.0 * N;  // closing sweep: t, u, basis read; v, u written
+    launches[KRY_K_MGS_LAST] += 1;
+  }
+  // one normalisation per chain step (one in all after the one-sweep steps) + ||b|| and v_0 = b/||b||
+  bytes[KRY_K_NORMALIZE] = 2.0 * N * (fused ? chain_steps + 1 : m) + 3.0 * N;
+  launches[KRY_K_NORMALIZE] = (fused ? chain_steps + 1 : m) + 2;
   bytes[KRY_K_COMBINE] = (m + 1) * N;
   launches[KRY_K_COMBINE] = 1;
   if (g->flags & KRY_GMRES_TDP) {
@@ -1297,6 +1393,7 @@ int kry_ie_create_slab(kry_ctx *ctx, double c1x, double c1y, double c2x, double 
     op->n = ie->nloc;
     for (int b = 0; b < 5; b++) op->band[b] = ie->band[b];
     op->own_bands = false;
+    op->wrap_free = true;  // k_offdiag / k_assemble leave the ghost columns' outward couplings at zero
     op->slab = !ie->whole();
     ie->op = op;
     if (m > 0) st = gmres_create(ctx, ie->nloc, m, flags, P, &ie->solver);

@@ -1,0 +1,375 @@
+// One-sweep Arnoldi step for the 5-band stencil operator (gfx950).
+//
+// The plain chain of include/solver.hpp:196-211 reads the basis twice per
+// step: once for the dot products <w, v_k>, once for w -= h_k v_k.  The sweep
+// below reads it once.  Per step i it consumes the un-normalised new vector
+// u_i and t_i = A u_i that the previous sweep left behind, and in ONE pass over
+// the grid
+//     v_i     = u_i / ||u_i||                       (stored as basis vector i)
+//     w       = t_i / ||u_i||                       (= A v_i up to rounding)
+//     u_{i+1} = w - h_0 v_0 - ... - h_i v_i         (modified Gram-Schmidt order)
+//     t_{i+1} = A u_{i+1}
+// and accumulates <t_{i+1}, v_k>, <t_{i+1}, u_{i+1}>, <v_k, u_{i+1}> (k <= i)
+// and <u_{i+1}, u_{i+1}>.  From those sums the next step's coefficients follow
+// without touching a vector again (k_fused_coeffs): with n = ||u_{i+1}||,
+//     <A v_{i+1}, v_k> = <t, v_k> / n,   <A v_{i+1}, v_{i+1}> = <t, u> / n^2,
+//     <v_k, v_{i+1}>   = <v_k, u> / n    (the carried Gram column),
+// and the modified-Gram-Schmidt coefficients are recovered from the dots of the
+// un-updated w and the Gram matrix, h_k = d_k - sum_{a<k} h_a g_ak, exactly as
+// the blocked sweeps do within one group.
+//
+// t = A u needs u at the four neighbours, so the sweep is tiled in two
+// dimensions: a workgroup owns a strip of at most 254 columns (thread = column,
+// one halo column on either side) and walks down a band of rows, keeping the
+// last rows of u in LDS; u is recomputed on the band's two halo rows and the
+// strip's two halo columns (about 1.5 % extra reads).  The basis values of a row
+// are needed once more one row later (for the dots with t), and wait in LDS.
+//
+// Requirements, checked by the host: one rank, 5-band operator whose couplings
+// across the ends of a grid row (band s in column 0, band n in the last
+// column) are zero, m <= kFusedMaxM.
+#include "kry_device.h"
+
+namespace kry {
+
+namespace {
+
+constexpr int kStripMax = kBlock - 2;  // owned columns per workgroup
+
+struct FusedGeom {
+  int rows, P;     // padded grid: rows x P, unknown k = row * P + column
+  int W, nstrips;  // owned columns per strip, strips per row
+  int R, nbands;   // rows per band, bands
+};
+
+// Stencil row sum in ascending column order starting from +0.0, as k_spmv_stencil.
+__device__ __forceinline__ double row_sum(double cw, double cs, double cc, double cn, double ce, double xw,
+                                          double xs, double xc, double xn, double xe) {
+  double r = 0.0;
+  r = r + cw * xw;
+  r = r + cs * xs;
+  r = r + cc * xc;
+  r = r + cn * xn;
+  r = r + ce * xe;
+  return r;
+}
+
+// Value of x in lane `lane` (a compile-time constant after unrolling), as a wave-uniform scalar.
+__device__ __forceinline__ double lane_value(double x, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// NV: basis vectors already normalised (v_0..v_{NV-1}, read from V); the vector
+// being normalised in this sweep is number NV.
+// part layout (q * gridDim.x + workgroup): q <= NV: <t, v_q>;  NV+1: <t, u>;
+// NV+2+a, a <= NV: <v_a, u>;  2 NV + 3: <u, u>.
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b,
+                                                           const double *__restrict__ V, int64_t ld,
+                                                           const double *__restrict__ t_in,
+                                                           const double *__restrict__ u_in,
+                                                           const double *__restrict__ coef,
+                                                           double *__restrict__ v_out,
+                                                           double *__restrict__ u_out,
+                                                           double *__restrict__ t_out,
+                                                           double *__restrict__ part) {
+  constexpr int NQ = 2 * NV + 4;
+  extern __shared__ double lds[];
+  double *keep = lds;                              // (NV + 1) x kBlock: v_k and v_NV of the previous row
+  double *ring = keep + (size_t)(NV + 1) * kBlock;  // 4 x kBlock: the last rows of u
+  double *red = ring + 4 * kBlock;                 // NQ x 4
+  const int t = threadIdx.x;
+  const int strip = blockIdx.x % geo.nstrips, band = blockIdx.x / geo.nstrips;
+  const int cs = strip * geo.W;
+  const int ce = cs + geo.W < geo.P ? cs + geo.W : geo.P;
+  const int c = cs - 1 + t;
+  const bool colvalid = c >= 0 && c < geo.P && t <= (ce - cs) + 1;
+  const bool colowned = t >= 1 && c < ce;
+  const int rs = band * geo.R;
+  const int re = rs + geo.R < geo.rows ? rs + geo.R : geo.rows;
+  const int P = geo.P;
+
+  // the coefficients live in the lanes of one register pair (lane k: h_k)
+  static_assert(NV + 1 <= 64, "one coefficient per lane");
+  const double hpack = coef[(t & 63) <= NV ? (t & 63) : 0];
+  const double nrm = coef[kFusedNormSlot];
+
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+#pragma unroll
+  for (int k = 0; k <= NV; k++) keep[k * kBlock + t] = 0.0;
+
+  // Loads run one row ahead of the arithmetic: the values of row rr + 1 are requested
+  // before row rr is worked on.
+  double vn[NV > 0 ? NV : 1];
+  double tin_n = 0.0, uin_n = 0.0;
+  double bn[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  auto fetch = [&](int rr) {
+    const bool rowvalid = rr >= 0 && rr < geo.rows;
+    const int64_t idx = (int64_t)rr * P + c;
+    tin_n = 0.0;
+    uin_n = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) vn[k] = 0.0;
+    if (rowvalid && colvalid) {
+      tin_n = __builtin_nontemporal_load(&t_in[idx]);
+      uin_n = __builtin_nontemporal_load(&u_in[idx]);
+#pragma unroll
+      for (int k = 0; k < NV; k++) vn[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idx]);
+    }
+    // operator coefficients of row rr - 1, whose application completes one round later
+    if (rr - 1 >= rs && rr - 1 < re && colowned) {
+      const int64_t idq = idx - P;
+      bn[0] = __builtin_nontemporal_load(&b.w[idq]);
+      bn[1] = __builtin_nontemporal_load(&b.s[idq]);
+      bn[2] = __builtin_nontemporal_load(&b.c[idq]);
+      bn[3] = __builtin_nontemporal_load(&b.n[idq]);
+      bn[4] = __builtin_nontemporal_load(&b.e[idq]);
+    }
+  };
+  fetch(rs - 1);
+
+  for (int rr = rs - 1; rr <= re; rr++) {
+    const bool rowvalid = rr >= 0 && rr < geo.rows;
+    const int64_t idx = (int64_t)rr * P + c;
+    const int q = rr - 1;  // the row whose operator application completes in this round
+    const bool emit = q >= rs && colowned;
+    const int64_t idq = idx - P;
+    double vk[NV > 0 ? NV : 1];
+#pragma unroll
+    for (int k = 0; k < NV; k++) vk[k] = vn[k];
+    const double tin = tin_n, uin = uin_n;
+    const double cw = bn[0], cso = bn[1], cc = bn[2], cn = bn[3], cea = bn[4];
+    if (rr < re) fetch(rr + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the arithmetic below
+    double vi = 0.0, u = 0.0;
+    if (rowvalid && colvalid) {
+      vi = uin / nrm;
+      u = tin / nrm;
+#pragma unroll
+      for (int k = 0; k < NV; k++) u = u - lane_value(hpack, k) * vk[k];
+      u = u - lane_value(hpack, NV) * vi;
+    }
+    if (rr >= rs && rr < re && colowned) {
+      if (v_out) v_out[idx] = vi;
+      u_out[idx] = u;
+#pragma unroll
+      for (int k = 0; k < NV; k++) acc[NV + 2 + k] = fma(vk[k], u, acc[NV + 2 + k]);
+      acc[2 * NV + 2] = fma(vi, u, acc[2 * NV + 2]);
+      acc[2 * NV + 3] = fma(u, u, acc[2 * NV + 3]);
+    }
+    const int slot = (rr - rs + 1) & 3;
+    ring[slot * kBlock + t] = u;
+    __syncthreads();
+    if (emit) {
+      const double *rq = ring + ((slot + 3) & 3) * kBlock;   // row q
+      const double *rm = ring + ((slot + 2) & 3) * kBlock;   // row q - 1
+      const double *rp = ring + slot * kBlock;               // row q + 1
+      // the first and last column of a grid row have no left / right neighbour in that row
+      const double xs = c > 0 ? rq[t - 1] : 0.0;
+      const double xn = c + 1 < P ? rq[t + 1] : 0.0;
+      const double uq = rq[t];
+      const double tv = row_sum(cw, cso, cc, cn, cea, rm[t], xs, uq, xn, rp[t]);
+      __builtin_nontemporal_store(tv, &t_out[idq]);
+#pragma unroll
+      for (int k = 0; k <= NV; k++) acc[k] = fma(keep[k * kBlock + t], tv, acc[k]);
+      acc[NV + 1] = fma(uq, tv, acc[NV + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) keep[k * kBlock + t] = vk[k];
+    keep[NV * kBlock + t] = vi;
+  }
+  reduce_store_multi<NQ>(acc, red, part);
+}
+
+// Last step of a cycle: v_i, u_{i+1} and <u_{i+1}, u_{i+1}> only (no operator
+// application follows).  part[workgroup].
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restrict__ V, int64_t ld,
+                                                           const double *__restrict__ t_in,
+                                                           const double *__restrict__ u_in,
+                                                           const double *__restrict__ coef,
+                                                           double *__restrict__ v_out,
+                                                           double *__restrict__ u_out, int64_t n,
+                                                           double *__restrict__ part) {
+  __shared__ double s[kBlock / 64];
+  double h[NV + 1];
+#pragma unroll
+  for (int k = 0; k <= NV; k++) h[k] = coef[k];
+  const double nrm = coef[kFusedNormSlot];
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    double vk[NV > 0 ? NV : 1];
+    const double tin = __builtin_nontemporal_load(&t_in[i]);
+    const double uin = __builtin_nontemporal_load(&u_in[i]);
+#pragma unroll
+    for (int k = 0; k < NV; k++) vk[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i]);
+    const double vi = uin / nrm;
+    double u = tin / nrm;
+#pragma unroll
+    for (int k = 0; k < NV; k++) u = u - h[k] * vk[k];
+    u = u - h[NV] * vi;
+    if (v_out) v_out[i] = vi;
+    u_out[i] = u;
+    a = fma(u, u, a);
+  }
+  const double tot = block_sum(a, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// tot[q] = sum of part[q * np .. q * np + np): one workgroup per quantity.
+__global__ __launch_bounds__(kBlock) void k_reduce_parts_wide(const double *__restrict__ part, int np,
+                                                               double *__restrict__ tot) {
+  __shared__ double s[kBlock / 64];
+  const int q = blockIdx.x;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < np; i += kBlock) a += part[(size_t)q * np + i];
+  const double r = block_sum(a, s);
+  if (threadIdx.x == 0) tot[q] = r;
+}
+
+// Coefficients of step i from the totals of the sweep that produced u_i and
+// t_i = A u_i (layout of k_arnoldi_fused<i-1>), or, with boot, from the totals
+// of the operator kernel applied to the normalised v_i (i + 1 dots, then the i
+// Gram entries of v_i).  Stores column i of G and of H, H[i][i-1] = ||u_i||,
+// coef[0..i] = h and coef[kFusedNormSlot] = ||u_i|| (1 with boot).
+__global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ tot, int i, int boot,
+                                                      double *__restrict__ G, int gld,
+                                                      double *__restrict__ H, int m,
+                                                      double *__restrict__ coef) {
+  __shared__ double gs[kFusedMaxM * kFusedMaxM];
+  const int lane = threadIdx.x;
+  const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
+  // earlier Gram columns
+  for (int e = lane; e < i * i; e += 64) {
+    const int a = e / i, k = e % i;
+    gs[a * kFusedMaxM + k] = a < k ? G[(size_t)a * gld + k] : 0.0;
+  }
+  if (lane < i) {
+    const double g = boot ? tot[i + 1 + lane] : tot[i + 1 + lane] / nrm;
+    gs[lane * kFusedMaxM + i] = g;
+    G[(size_t)lane * gld + i] = g;
+  }
+  __syncthreads();
+  double v = 0.0;
+  if (lane <= i) {
+    if (boot)
+      v = tot[lane];
+    else
+      v = lane < i ? tot[lane] / nrm : tot[i] / nrm / nrm;
+  }
+  for (int a = 0; a < i; a++) {
+    const double ha = __shfl(v, a, 64);
+    if (lane > a && lane <= i) v = v - ha * gs[a * kFusedMaxM + lane];
+  }
+  if (lane <= i) {
+    coef[lane] = v;
+    H[(size_t)lane * m + i] = v;
+  }
+  if (lane == 0) {
+    coef[kFusedNormSlot] = nrm;
+    if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
+  }
+}
+
+FusedGeom fused_geom(int rows, int P) {
+  FusedGeom g;
+  g.rows = rows;
+  g.P = P;
+  g.nstrips = (P + kStripMax - 1) / kStripMax;
+  g.W = (P + g.nstrips - 1) / g.nstrips;
+  // about four workgroups per compute unit, bands of at least 32 rows
+  int nb = (4 * 256) / g.nstrips;
+  if (nb < 1) nb = 1;
+  while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
+  g.R = (rows + nb - 1) / nb;
+  g.nbands = (rows + g.R - 1) / g.R;
+  return g;
+}
+
+template <int NV>
+void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
+                    const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
+                    double *t_out, double *part) {
+  constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 4 * kBlock + (2 * NV + 4) * (kBlock / 64));
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld,
+                     t_in, u_in, coef, v_out, u_out, t_out, part);
+}
+
+template <int NV>
+void launch_close_t(hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
+                    const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
+  hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(grid), dim3(kBlock), 0, st, V, ld, t_in, u_in, coef, v_out, u_out,
+                     n, part);
+}
+
+template <int NV = kFusedMaxM - 1>
+struct FusedTable {
+  static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
+                    const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
+                    double *t_out, double *part) {
+    if (nv == NV)
+      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part);
+    else
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part);
+  }
+  static void close(int nv, hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
+                    const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
+    if (nv == NV)
+      launch_close_t<NV>(st, V, ld, t_in, u_in, coef, v_out, u_out, n, part, grid);
+    else
+      FusedTable<NV - 1>::close(nv, st, V, ld, t_in, u_in, coef, v_out, u_out, n, part, grid);
+  }
+};
+
+template <>
+struct FusedTable<-1> {
+  static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const double *, int64_t, const double *,
+                    const double *, const double *, double *, double *, double *, double *) {}
+  static void close(int, hipStream_t, const double *, int64_t, const double *, const double *, const double *,
+                    double *, double *, int64_t, double *, int) {}
+};
+
+}  // namespace
+
+int fused_parts(int rows, int cols) {
+  const FusedGeom g = fused_geom(rows, cols);
+  return g.nstrips * g.nbands;
+}
+
+void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
+                          const double *t_in, const double *u_in, const double *coef, double *v_out,
+                          double *u_out, double *t_out, double *part, int *nparts) {
+  const FusedGeom g = fused_geom(rows, cols);
+  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part);
+  *nparts = g.nstrips * g.nbands;
+}
+
+void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in,
+                          const double *u_in, const double *coef, double *v_out, double *u_out, int64_t n,
+                          double *part, int *nparts) {
+  int grid = grid_for(n);
+  if (grid > 1024) grid = 1024;
+  FusedTable<>::close(nv, st, V, ld, t_in, u_in, coef, v_out, u_out, n, part, grid);
+  *nparts = grid;
+}
+
+void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot) {
+  hipLaunchKernelGGL(k_reduce_parts_wide, dim3(nq), dim3(kBlock), 0, st, part, np, tot);
+}
+
+void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
+                         int m, double *coef) {
+  hipLaunchKernelGGL(k_fused_coeffs, dim3(1), dim3(64), 0, st, tot, i, boot ? 1 : 0, G, gld, H, m, coef);
+}
+
+}  // namespace kry

@@ -15,6 +15,10 @@ constexpr int kMaxParts = 2048;    // partial sums per reduction buffer
 constexpr int kMaxM = 256;         // largest Krylov dimension supported
 constexpr int kMgsBlock = 32;      // most Gram-Schmidt links fused into one sweep over w
 constexpr int kMaxRed = 2 * kMgsBlock - 1;  // partial-sum arrays per pass: dots + Gram column of the last vector
+constexpr int kFusedMaxM = 50;     // largest Krylov dimension served by the one-sweep Arnoldi step
+constexpr int kFusedNormSlot = kFusedMaxM;  // coefficient array: h_0..h_i, then ||u_i|| in this slot
+constexpr int kFusedCoef = kFusedMaxM + 2;
+constexpr int kFusedRed = 2 * kFusedMaxM + 4;  // partial-sum arrays of one fused sweep (upper bound)
 
 // Five coefficient bands of a stencil operator on a rows x cols padded grid.
 struct Bands {
@@ -113,6 +117,27 @@ void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t
                             const double *val, int64_t n, double *lo, double *di, double *up);
 
 void launch_fill(hipStream_t st, double *x, double v, int64_t n);
+
+// ---- one-sweep Arnoldi step (stencil operator, one rank) ---------------------
+// Workgroups (= partial sums per quantity) of a fused sweep over a rows x cols grid.
+int fused_parts(int rows, int cols);
+// Step nv of a cycle: normalise u_in into v_out (basis vector nv; nullptr: u_in is
+// already normalised and stored), orthogonalise t_in / ||u_in|| against the nv + 1
+// vectors with the coefficients coef[0..nv], store the new vector in u_out, A times
+// it in t_out, and the 2 nv + 4 partial sums (see k_arnoldi_fused) in part.
+void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
+                          const double *t_in, const double *u_in, const double *coef, double *v_out,
+                          double *u_out, double *t_out, double *part, int *nparts);
+// The same without the operator application and the dots: only <u_out, u_out> in part.
+void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in,
+                          const double *u_in, const double *coef, double *v_out, double *u_out, int64_t n,
+                          double *part, int *nparts);
+// tot[q] = sum_i part[q * np + i], one workgroup per quantity
+void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot);
+// Coefficients of step i from the totals of the previous sweep (boot: of the operator
+// kernel applied to the stored, normalised v_i); see k_fused_coeffs.
+void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
+                         int m, double *coef);
 
 // ---- implicit-Euler assembly ------------------------------------------------
 struct IeGeom {

@@ -14,8 +14,9 @@
 //    reductions, whose summation order differs from the reference anyway.
 #include <stdlib.h>
 
-#include "kry_internal.h"
 #include <cstdlib>
+
+#include "kry_device.h"
 
 namespace kry {
 
@@ -26,93 +27,12 @@ static thread_local const int *t_stop = nullptr;
 LaunchPredicate::LaunchPredicate(const int *stop) : saved_(t_stop) { t_stop = stop; }
 LaunchPredicate::~LaunchPredicate() { t_stop = saved_; }
 
-// true when the solver this launch belongs to has already met its tolerance
-__device__ __forceinline__ bool stopped(const int *__restrict__ stop) { return stop != nullptr && *stop != 0; }
-
 int grid_for(int64_t items) {
   int64_t b = (items + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
   if (b > kMaxGrid) b = kMaxGrid;
   return (int)b;
 }
-
-// ---------------------------------------------------------------------------
-// Reduction helpers
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;  // lane 0 holds the wave total
-}
-
-// Sum over the workgroup, returned to every thread.  `s` holds kBlock/64 doubles.
-__device__ __forceinline__ double block_sum(double v, double *s) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) s[wv] = v;
-  __syncthreads();
-  double t = s[0];
-#pragma unroll
-  for (int i = 1; i < kBlock / 64; i++) t += s[i];
-  return t;
-}
-
-// Total of a partial-sum array; every workgroup of every kernel evaluates the
-// same expression tree, so all of them obtain the same bits.
-__device__ __forceinline__ double sum_parts(const double *__restrict__ part, int np, double *s) {
-  double a = 0.0;
-  for (int i = threadIdx.x; i < np; i += kBlock) a += part[i];
-  return block_sum(a, s);
-}
-
-__device__ __forceinline__ double nan_max(double a, double b) {
-  // max that keeps a NaN once one has been seen
-  return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b);
-}
-
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ d2 ld_nt(const d2 *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_nt(d2 v, d2 *p) { __builtin_nontemporal_store(v, p); }
-
-// partial-sum arrays of a group of k vectors: k dot products with the work vector and the
-// k - 1 Gram entries <c_a, c_{k-1}> of the group's last vector
-constexpr int nred(int k) { return k > 0 ? 2 * k - 1 : 0; }
-
-// Totals of NQ partial-sum arrays, evaluated by the same expression tree in
-// every workgroup: wave q % 4 reduces array q with its 64 lanes.
-template <int NQ>
-__device__ __forceinline__ void sum_parts_multi(const double *__restrict__ part, int np, double *tot /* LDS, NQ */) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int q = wv; q < NQ; q += kBlock / 64) {
-    double a = 0.0;
-    for (int i = lane; i < np; i += 64) a += part[(size_t)q * np + i];
-    a = wave_sum(a);
-    if (lane == 0) tot[q] = a;
-  }
-  __syncthreads();
-}
-
-// Block-level reduction of NQ accumulators into part[q * gridDim.x + blockIdx.x].
-template <int NQ>
-__device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? NQ : 1], double *red /* LDS NQ*4 */,
-                                                    double *__restrict__ part) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < NQ; q++) {
-    const double t = wave_sum(acc[q]);
-    if (lane == 0) red[q * (kBlock / 64) + wv] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < NQ) {
-    double t = red[threadIdx.x * (kBlock / 64)];
-#pragma unroll
-    for (int i = 1; i < kBlock / 64; i++) t += red[threadIdx.x * (kBlock / 64) + i];
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
-  }
-}
-
 
 // ---------------------------------------------------------------------------
 // BLAS-1 shaped kernels

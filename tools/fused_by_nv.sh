@@ -1,0 +1,21 @@
+#!/bin/bash
+# Per-instantiation durations of the one-sweep Arnoldi kernels (rocprofv3 kernel trace over two steps).
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/fused_nv
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > $OUT/bench.json 2> $OUT/err.txt
+python3 - <<PY
+import csv, glob, re
+f = glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True)[0]
+rows = []
+for r in csv.DictReader(open(f)):
+    m = re.search(r"k_arnoldi_fused<(\d+)>", r["Name"])
+    if m:
+        rows.append((int(m.group(1)), float(r["AverageNs"]) / 1e3, int(r["Calls"])))
+N = 8.0 * 8194 * 8194
+for nv, us, calls in sorted(rows):
+    b = (2.0 + nv + 5.0 + 3.0) * N
+    print("NV=%2d  %8.1f us  %6.1f GB/s  calls %d" % (nv, us, b / us / 1e3, calls))
+PY
