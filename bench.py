@@ -235,6 +235,7 @@ def main():
                                   if args.tdp else ""),
                    "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
                    "mgs_block": dev.solver().get_mgs_block(),
+                   "one_sweep_from": dev.solver().get_one_sweep(),
                    "parallelism": "1 GPU", "graph": bool(args.graph),
                    "solver_mode": ("restarted, residual-monitored, rtol %g" % args.extended) if args.extended > 0.0
                    else "reference: one fixed cycle of m steps"},

@@ -178,6 +178,21 @@ const double *kry_gmres_result_device(kry_gmres *g);
  * once, in the step that creates v_k, and carried in a small matrix. */
 int kry_gmres_set_mgs_block(kry_gmres *g, int k);
 int kry_gmres_get_mgs_block(const kry_gmres *g);
+/* One-sweep Arnoldi steps.  The chain of include/solver.hpp:196-211 reads the
+ * basis twice per step (dot products, then updates).  From step `first_step` of
+ * every cycle on, kry_gmres_solve* instead uses sweeps that read it once: each
+ * normalises the newest vector, applies all coefficients, applies the operator
+ * to the un-normalised result and takes every dot product of the following
+ * step, whose coefficients are then recovered from those sums and the carried
+ * Gram matrix as above.  Same Krylov space and Hessenberg matrix up to rounding.
+ * Available on one rank for a 5-band operator without couplings across the ends
+ * of a grid row, plain mode (no preconditioner, not KRY_GMRES_EXTENDED) and
+ * 3 <= m <= 50; otherwise, and for kry_gmres_add_arnoldi, the chain is used.
+ * first_step < 0 switches the sweeps off; values above min(m - 2, 31) are clamped.
+ * Default 2 (environment override: KRY_FUSED_FROM).  The getter returns -1 when
+ * the sweeps are off or unavailable for this solver. */
+int kry_gmres_set_one_sweep(kry_gmres *g, int first_step);
+int kry_gmres_get_one_sweep(const kry_gmres *g);
 int64_t kry_gmres_size(const kry_gmres *g);
 int kry_gmres_iterations(const kry_gmres *g);
 /* KRY_GMRES_EXTENDED only; no counterpart in the reference, whose solve always

@@ -678,6 +678,11 @@ int kry_op_apply(kry_op *op, const double *x_host, double *y_host) {
 // ---------------------------------------------------------------------------
 static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld + g->halo; }
 
+// Latest step at which the one-sweep kernels can take over: the hand-over applies the
+// operator with the dots of all earlier vectors in one kernel (at most kMgsBlock of
+// them), and at least one full sweep has to follow before the closing one.
+static int fused_from_max(int m) { return m - 2 < kMgsBlock - 1 ? m - 2 : kMgsBlock - 1; }
+
 extern "C" {
 
 static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out);
@@ -739,18 +744,16 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   }
   if (st == KRY_OK && !(flags & (KRY_GMRES_EXTENDED | KRY_GMRES_TDP)) && ctx->nranks == 1 &&
       m <= kFusedMaxM && m >= 3) {
-    int from = 8;
+    int from = 2;
     if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
-    if (from >= 0 && from > m - 2) from = m - 2;
-    if (from >= 0) {
-      st = dev_alloc(&g->fu[0], g->ld);
-      if (st == KRY_OK) st = dev_alloc(&g->fu[1], g->ld);
-      if (st == KRY_OK) st = dev_alloc(&g->fw, g->ld);
-      if (st == KRY_OK) st = dev_alloc(&g->fparts, (int64_t)kFusedRed * kMaxParts);
-      if (st == KRY_OK) st = dev_alloc(&g->ftot, kFusedRed);
-      if (st == KRY_OK) st = dev_alloc(&g->fcoef, kFusedCoef);
-      if (st == KRY_OK) g->fused_from = from;
-    }
+    if (from > fused_from_max(m)) from = fused_from_max(m);
+    st = dev_alloc(&g->fu[0], g->ld);
+    if (st == KRY_OK) st = dev_alloc(&g->fu[1], g->ld);
+    if (st == KRY_OK) st = dev_alloc(&g->fw, g->ld);
+    if (st == KRY_OK) st = dev_alloc(&g->fparts, (int64_t)kFusedRed * kMaxParts);
+    if (st == KRY_OK) st = dev_alloc(&g->ftot, kFusedRed);
+    if (st == KRY_OK) st = dev_alloc(&g->fcoef, kFusedCoef);
+    if (st == KRY_OK) g->fused_from = from < 0 ? -1 : from;
   }
   if (st != KRY_OK) {
     kry_gmres_destroy(g);
@@ -808,6 +811,20 @@ int kry_gmres_set_mgs_block(kry_gmres *g, int k) {
 }
 
 int kry_gmres_get_mgs_block(const kry_gmres *g) { return g ? g->kblock : 0; }
+
+int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
+  if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (first_step < 0) {
+    g->fused_from = -1;
+    return KRY_OK;
+  }
+  if (!g->fu[0])
+    return fail(KRY_ERR_STATE, "one-sweep steps need one rank, plain mode and 3 <= num_iters <= %d", kFusedMaxM);
+  g->fused_from = first_step > fused_from_max(g->m) ? fused_from_max(g->m) : first_step;
+  return KRY_OK;
+}
+
+int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fu[0] ? g->fused_from : -1; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");

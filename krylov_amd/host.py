@@ -191,6 +191,13 @@ class GMRESSolver:
     def get_mgs_block(self):
         return capi.lib().kry_gmres_get_mgs_block(self.h)
 
+    def set_one_sweep(self, first_step):
+        """First Arnoldi step of a cycle that uses the one-sweep kernels (< 0: never)."""
+        check(capi.lib().kry_gmres_set_one_sweep(self.h, first_step))
+
+    def get_one_sweep(self):
+        return capi.lib().kry_gmres_get_one_sweep(self.h)
+
     def cycle_bytes(self, op):
         b = (C.c_double * capi.K_COUNT)()
         l = (C.c_int * capi.K_COUNT)()
@@ -214,11 +221,13 @@ class ImplicitEuler:
 
     def __init__(self, ctx, corner1, corner2, cx, cy, init, params, bcs, m, tdp=False,
                  fixed_preconditioning=False, use_graph=False, bc_time_dependent=True, mgs_block=None,
-                 row_range=None, extended=None):
+                 row_range=None, extended=None, one_sweep=None):
         """row_range=(begin, end): own only these padded rows of the mesh (one
         rank of a row-block decomposition; the context needs collectives).
         extended=(rtol, max_cycles): solve every step with the restarted,
-        residual-monitored GMRES(m) instead of the reference's fixed cycle."""
+        residual-monitored GMRES(m) instead of the reference's fixed cycle.
+        one_sweep: first Arnoldi step served by the one-sweep kernels (< 0: none;
+        None: the library's default)."""
         L = capi.lib()
         self.ctx, self.cx, self.cy, self.m, self.tdp = ctx, cx, cy, m, tdp
         self.row_range = (0, cx + 2) if row_range is None else (int(row_range[0]), int(row_range[1]))
@@ -261,6 +270,8 @@ class ImplicitEuler:
             check(L.kry_gmres_set_mgs_block(L.kry_ie_solver(h), mgs_block))
         if extended is not None:
             check(L.kry_gmres_set_tolerance(L.kry_ie_solver(h), float(extended[0]), int(extended[1])))
+        if one_sweep is not None and m > 0:
+            check(L.kry_gmres_set_one_sweep(L.kry_ie_solver(h), int(one_sweep)))
         self._bc_pushed = False
         self._push_bc_values(0.0)
         check(L.kry_ie_init_offdiag(h))

@@ -243,14 +243,33 @@ def test_ghost_fill_and_assembly_bit_exact(ctx, oracle, name, make, shape):
 
 # ---- GMRES against the restatement -------------------------------------------------
 
-@pytest.mark.parametrize("block", [1, 4, 8, 16, 32])
+# Gram-Schmidt variants: ("chain", K) = K links per sweep over the work vector, the
+# basis read twice per step; ("sweep", s) = one-sweep steps from step s of the cycle on
+VARIANTS = [("chain", 1), ("chain", 4), ("chain", 8), ("chain", 16), ("chain", 32),
+            ("sweep", 0), ("sweep", 2), ("sweep", 7)]
+
+
+def variant_kwargs(variant):
+    kind, val = variant
+    return {"mgs_block": val, "one_sweep": -1} if kind == "chain" else {"one_sweep": val}
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "%s%d" % v)
 @pytest.mark.parametrize("m,tdp", [(2, False), (10, False), (30, False), (50, False), (10, True), (30, True)])
-def test_gmres_cycle_matches_reference(ctx, oracle, m, tdp, block):
+def test_gmres_cycle_matches_reference(ctx, oracle, m, tdp, variant):
     """One fixed-m cycle on the assembled prob1 system: Hessenberg matrix,
     basis and solution against the CPU restatement, with the plain
-    Gram-Schmidt chain (block 1) and with four links fused per sweep."""
+    Gram-Schmidt chain (1 link per sweep), with several links fused per sweep,
+    and with the one-sweep Arnoldi steps (which need m >= 3 and no
+    preconditioner; elsewhere the request falls back to the chain)."""
     ref = oracle.ImplicitEuler(**problems.prob1(), m=m, tdp=tdp)
-    dev = host.ImplicitEuler(ctx, **problems.prob1(), m=m, tdp=tdp, mgs_block=block)
+    if variant[0] == "sweep" and (tdp or m < 3):
+        with pytest.raises(capi.KrylovError):
+            host.ImplicitEuler(ctx, **problems.prob1(), m=m, tdp=tdp, **variant_kwargs(variant))
+        return
+    dev = host.ImplicitEuler(ctx, **problems.prob1(), m=m, tdp=tdp, **variant_kwargs(variant))
+    if variant[0] == "sweep":
+        assert dev.solver().get_one_sweep() == min(variant[1], m - 2, 31)
     ref.assemble_system(0.25)
     dev.assemble_system(0.25)
     b = ref.sol_vec()
@@ -294,7 +313,7 @@ def test_blocked_gram_schmidt_equals_chain(ctx, oracle, shape):
     x_ref = ref.solver().solve(ref.op(), ref.sol_vec())
     Href = ref.solver().hessenberg_matrix()
     for block in (1, 2, 3, 4, 8, 16, 32):
-        dev = host.ImplicitEuler(ctx, **problems.s_iso(*shape), m=35, mgs_block=block)
+        dev = host.ImplicitEuler(ctx, **problems.s_iso(*shape), m=35, mgs_block=block, one_sweep=-1)
         dev.assemble_system(0.25)
         g = dev.solver()
         x = dev.compact(g.solve(dev.operator(), dev.expand(dev.sol_vec())))
@@ -302,6 +321,90 @@ def test_blocked_gram_schmidt_equals_chain(ctx, oracle, shape):
         assert np.max(np.abs(H[:, :18] - Href[:, :18])) <= 1e-12 * np.max(np.abs(Href)), block
         assert np.max(np.abs(H - Href)) <= 1e-9 * np.max(np.abs(Href)), block
         assert rel(x, x_ref) <= 1e-12, block
+
+
+@pytest.mark.parametrize("shape,m", [((40, 30), 35), ((21, 13), 35), ((300, 260), 50), ((5, 700), 50), ((2, 3), 3)])
+def test_one_sweep_steps_equal_chain(ctx, oracle, shape, m):
+    """The one-sweep Arnoldi steps (basis read once per step) reproduce the
+    plain chain's Hessenberg matrix and solution to rounding level, whichever
+    step of the cycle they take over at: every kernel instantiation up to 48
+    earlier vectors, grids narrower and wider than one 254-column strip, bands
+    of rows that do and do not divide the grid.  Bars as for the blocked
+    sweeps above, or ten times the distance of the device's plain chain from
+    the CPU restatement where that is larger (larger grids)."""
+    ref = oracle.ImplicitEuler(**problems.s_iso(*shape), m=m)
+    ref.assemble_system(0.25)
+    x_ref = ref.solver().solve(ref.op(), ref.sol_vec())
+    Href = ref.solver().hessenberg_matrix()
+    well = min(18, m)
+    scale = np.max(np.abs(Href))
+    # yardstick: the distance of the device's plain chain from the CPU restatement
+    # (rounding of the dot products grows with the grid)
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(*shape), m=m, one_sweep=-1, mgs_block=1)
+    dev.assemble_system(0.25)
+    g = dev.solver()
+    x_chain = dev.compact(g.solve(dev.operator(), dev.expand(dev.sol_vec())))
+    H_chain = g.hessenberg_matrix()
+    bar_well = max(10.0 * np.max(np.abs(H_chain[:, :well] - Href[:, :well])), 1e-12 * scale)
+    bar_all = max(10.0 * np.max(np.abs(H_chain - Href)), 1e-9 * scale)
+    bar_x = max(10.0 * rel(x_chain, x_ref), 1e-12)
+    assert bar_x <= RTOL
+    for first in (0, 1, 2, 5, 17, 31, m - 2):
+        dev = host.ImplicitEuler(ctx, **problems.s_iso(*shape), m=m, one_sweep=first)
+        dev.assemble_system(0.25)
+        g = dev.solver()
+        assert g.get_one_sweep() == min(first, m - 2, 31)
+        x = dev.compact(g.solve(dev.operator(), dev.expand(dev.sol_vec())))
+        H = g.hessenberg_matrix()
+        assert np.max(np.abs(H[:, :well] - Href[:, :well])) <= bar_well, first
+        assert np.max(np.abs(H - Href)) <= bar_all, first
+        assert rel(x, x_ref) <= bar_x, first
+        if shape[0] * shape[1] >= m + 1:
+            V = np.stack([g.subspace_vector(k) for k in range(m + 1)])
+            assert np.max(np.abs(np.sum(V * V, axis=1) - 1.0)) <= 1e-13  # every vector is stored normalised
+
+
+def test_one_sweep_needs_a_grid_stencil(ctx, oracle):
+    """A 5-band operator that couples the last entry of one grid row with the
+    first entry of the next is not a 2-D stencil: the solver keeps to the chain
+    for it (and gets the same answer as the CPU restatement on the equivalent
+    general matrix); so does every CSR operator."""
+    rng = np.random.default_rng(5)
+    rows, cols, m = 12, 9, 10
+    n = rows * cols
+    w, s, nn, e = (rng.uniform(-0.3, 0.3, (rows, cols)) for _ in range(4))
+    c = 4.0 + rng.uniform(0.0, 1.0, (rows, cols))
+    A = np.zeros((n, n))
+    for k in range(n):
+        A[k, k] = c.flat[k]
+        if k >= cols:
+            A[k, k - cols] = w.flat[k]
+        if k >= 1:
+            A[k, k - 1] = s.flat[k]
+        if k + 1 < n:
+            A[k, k + 1] = nn.flat[k]
+        if k + cols < n:
+            A[k, k + cols] = e.flat[k]
+    b = rng.uniform(-1.0, 1.0, n)
+    x_ref = oracle.Gmres(n, m, False).solve(oracle.Op.dense(A), b)
+    g = host.GMRESSolver(ctx, n, m)
+    assert g.get_one_sweep() == 2
+    x = g.solve(host.Operator.stencil(ctx, w, s, c, nn, e), b)
+    assert rel(x, x_ref) <= RTOL
+    # the same bands without the couplings across row ends: now the sweeps run, same bar
+    s2, n2 = s.copy(), nn.copy()
+    s2[:, 0] = 0.0
+    n2[:, -1] = 0.0
+    for r in range(rows):
+        if r > 0:
+            A[r * cols, r * cols - 1] = 0.0
+        if r < rows - 1:
+            A[r * cols + cols - 1, r * cols + cols] = 0.0
+    x_ref = oracle.Gmres(n, m, False).solve(oracle.Op.dense(A), b)
+    for first in (-1, 0, 3):
+        g.set_one_sweep(first)
+        x = g.solve(host.Operator.stencil(ctx, w, s2, c, n2, e), b)
+        assert rel(x, x_ref) <= RTOL, first
 
 
 def test_gmres_general_matrix(ctx, oracle):
