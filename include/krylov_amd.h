@@ -185,9 +185,10 @@ int kry_gmres_get_mgs_block(const kry_gmres *g);
  * to the un-normalised result and takes every dot product of the following
  * step, whose coefficients are then recovered from those sums and the carried
  * Gram matrix as above.  Same Krylov space and Hessenberg matrix up to rounding.
- * Available on one rank for a 5-band operator without couplings across the ends
- * of a grid row, plain mode (no preconditioner, not KRY_GMRES_EXTENDED) and
- * 3 <= m <= 50; otherwise, and for kry_gmres_add_arnoldi, the chain is used.
+ * Available for a 5-band operator without couplings across the ends of a grid
+ * row (on several ranks: the row-block decomposition of kry_ie_create_slab),
+ * plain mode (no preconditioner, not KRY_GMRES_EXTENDED) and 3 <= m <= 50;
+ * otherwise, and for kry_gmres_add_arnoldi, the chain is used.
  * first_step < 0 switches the sweeps off; values above min(m - 2, 31) are clamped.
  * Default 2 (environment override: KRY_FUSED_FROM).  The getter returns -1 when
  * the sweeps are off or unavailable for this solver. */

@@ -742,7 +742,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
     if (st == KRY_OK) st = dev_alloc(&g->ud, g->ld);
   }
-  if (st == KRY_OK && !(flags & (KRY_GMRES_EXTENDED | KRY_GMRES_TDP)) && ctx->nranks == 1 &&
+  if (st == KRY_OK && !(flags & (KRY_GMRES_EXTENDED | KRY_GMRES_TDP)) &&
       m <= kFusedMaxM && m >= 3) {
     int from = 2;
     if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
@@ -766,10 +766,14 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
   (void)hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)g->ld, s);
   if (g->z) (void)hipMemsetAsync(g->z, 0, sizeof(double) * (size_t)g->ld, s);
+  for (double *p : {g->fu[0], g->fu[1], g->fw})
+    if (p) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)g->ld, s);
   // work vectors are addressed at their first owned entry from here on
   g->w += g->halo;
   g->vars += g->halo;
   if (g->z) g->z += g->halo;
+  for (double **p : {&g->fu[0], &g->fu[1], &g->fw})
+    if (*p) *p += g->halo;
   g->offset_applied = true;
   launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
   st = launch_ok("kry_gmres_create");
@@ -789,7 +793,8 @@ void kry_gmres_destroy(kry_gmres *g) {
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
                     g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
-                    g->dd, g->ud, g->R, g->G, g->fu[0], g->fu[1], g->fw, g->fparts, g->ftot, g->fcoef};
+                    g->dd, g->ud, g->R, g->G, g->fu[0] ? g->fu[0] - off : nullptr, g->fu[1] ? g->fu[1] - off : nullptr,
+                    g->fw ? g->fw - off : nullptr, g->fparts, g->ftot, g->fcoef};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
   if (g->ext_h) (void)hipHostFree(g->ext_h);
@@ -819,7 +824,7 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
     return KRY_OK;
   }
   if (!g->fu[0])
-    return fail(KRY_ERR_STATE, "one-sweep steps need one rank, plain mode and 3 <= num_iters <= %d", kFusedMaxM);
+    return fail(KRY_ERR_STATE, "one-sweep steps need plain mode (no preconditioner, not extended) and 3 <= num_iters <= %d", kFusedMaxM);
   g->fused_from = first_step > fused_from_max(g->m) ? fused_from_max(g->m) : first_step;
   return KRY_OK;
 }
@@ -1053,11 +1058,17 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
   return KRY_OK;
 }
 
-// The one-sweep steps need a true 2-D stencil on one rank and a grid that fits the
-// partial-sum buffers.
+// The one-sweep steps need a true 2-D stencil and a grid that fits the partial-sum buffers.
 static bool fused_usable(const kry_gmres *g, const kry_op *op) {
-  return g->fused_from >= 0 && op->kind == 0 && op->wrap_free && !op->slab && g->ctx->nranks == 1 &&
-         fused_parts(op->rows, op->cols) <= kMaxParts;
+  return g->fused_from >= 0 && op->kind == 0 && op->wrap_free && fused_parts(op->rows, op->cols) <= kMaxParts &&
+         (g->ctx->nranks == 1 || g->halo_row == op->cols);
+}
+
+// Totals of nq quantities from the partial sums of a one-sweep kernel, summed over the ranks.
+static int fused_totals(kry_gmres *g, int nq, int np) {
+  launch_reduce_parts_wide(g->ctx->stream, g->fparts, nq, np, g->ftot);
+  if (g->ctx->nranks > 1) KCHK(comm_allreduce(g->ctx, g->ftot, nq, KRY_REDUCE_SUM));
+  return KRY_OK;
 }
 
 // Steps fused_from .. m-1 of a cycle, one sweep over the basis each (kry_fused.hip).
@@ -1066,36 +1077,55 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   hipStream_t st = g->ctx->stream;
   const int m = g->m, i0 = g->fused_from;
   const int64_t n = g->n;
+  const int64_t P = op->cols;
+  const bool ranks = g->ctx->nranks > 1;
   const Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
   double *tb[2] = {g->w, g->fw};
   int np = 0;
+  if (g->halo_row > 0) KCHK(comm_halo(g->ctx, basis(g, i0), g->halo_row, n));
   {
     // t = A v_from with the dots against v_0..v_from and the Gram column of v_from
     ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
-    op_apply_async(op, basis(g, i0), tb[i0 & 1], i0 + 1, basis(g, 0), g->ld, g->fparts, &np, false);
+    op_apply_async(op, basis(g, i0), tb[i0 & 1], i0 + 1, basis(g, 0), g->ld, g->fparts, &np, g->halo_row > 0);
   }
-  launch_reduce_parts_wide(st, g->fparts, 2 * (i0 + 1) - 1, np, g->ftot);
+  KCHK(fused_totals(g, 2 * (i0 + 1) - 1, np));
   for (int i = i0; i < m; i++) {
     const bool boot = i == i0;
     launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef);
     const double *u_in = boot ? basis(g, i) : g->fu[i & 1];
     double *v_out = boot ? nullptr : basis(g, i);
+    double *u_out = g->fu[(i + 1) & 1];
     if (i < m - 1) {
+      if (ranks) {
+        // the new vector on this rank's first and last row, for the neighbours
+        ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+        for (int64_t off : {(int64_t)0, n - P}) {
+          launch_arnoldi_close(st, i, basis(g, 0) + off, g->ld, tb[i & 1] + off, u_in + off, g->fcoef, nullptr,
+                               u_out + off, P, g->fparts, &np);
+          if (n == P) break;
+        }
+        KCHK(comm_halo(g->ctx, u_out, P, n));
+      }
       {
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
         launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out,
-                             g->fu[(i + 1) & 1], tb[(i + 1) & 1], g->fparts, &np);
+                             u_out, tb[(i + 1) & 1], g->fparts, &np, ranks);
       }
-      launch_reduce_parts_wide(st, g->fparts, 2 * i + 4, np, g->ftot);
+      KCHK(fused_totals(g, 2 * i + 4, np));
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-      launch_arnoldi_close(st, i, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out, g->fu[(i + 1) & 1], n,
-                           g->fparts, &np);
+      launch_arnoldi_close(st, i, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out, u_out, n, g->fparts, &np);
     }
+  }
+  const double *pin = g->fparts;
+  if (ranks) {
+    KCHK(fused_totals(g, 1, np));
+    pin = g->ftot;
+    np = 1;
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
-    launch_scale_from(st, g->fu[m & 1], basis(g, m), g->fparts, np, n, g->H + (int64_t)m * m + (m - 1));
+    launch_scale_from(st, g->fu[m & 1], basis(g, m), pin, np, n, g->H + (int64_t)m * m + (m - 1));
   }
   g->nvec = m + 1;
   return launch_ok("one-sweep Arnoldi steps");

@@ -25,9 +25,15 @@
 // strip's two halo columns (about 1.5 % extra reads).  The basis values of a row
 // are needed once more one row later (for the dots with t), and wait in LDS.
 //
-// Requirements, checked by the host: one rank, 5-band operator whose couplings
-// across the ends of a grid row (band s in column 0, band n in the last
-// column) are zero, m <= kFusedMaxM.
+// On several ranks (row-block decomposition) the rows next to a rank's block
+// belong to its neighbours: the host first evaluates u_{i+1} on the block's
+// first and last row (k_arnoldi_close on those rows), exchanges them, and the
+// sweep reads the neighbours' rows from the halo of u_out instead of
+// recomputing them (has_halo).
+//
+// Requirements, checked by the host: 5-band operator whose couplings across
+// the ends of a grid row (band s in column 0, band n in the last column) are
+// zero, m <= kFusedMaxM.
 #include "kry_device.h"
 
 namespace kry {
@@ -72,9 +78,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
                                                            double *__restrict__ v_out,
-                                                           double *__restrict__ u_out,
+                                                           double *u_out,
                                                            double *__restrict__ t_out,
-                                                           double *__restrict__ part) {
+                                                           double *__restrict__ part, int has_halo) {
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
   double *keep = lds;                              // (NV + 1) x kBlock: v_k and v_NV of the previous row
@@ -152,6 +158,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 #pragma unroll
       for (int k = 0; k < NV; k++) u = u - lane_value(hpack, k) * vk[k];
       u = u - lane_value(hpack, NV) * vi;
+    } else if (has_halo && !rowvalid && c >= 0 && c < P) {
+      // the neighbouring rank's boundary row of the new vector (zeros beyond the mesh)
+      u = u_out[idx];
     }
     if (rr >= rs && rr < re && colowned) {
       if (v_out) v_out[idx] = vi;
@@ -293,7 +302,7 @@ FusedGeom fused_geom(int rows, int P) {
 template <int NV>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
                     const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
-                    double *t_out, double *part) {
+                    double *t_out, double *part, int has_halo) {
   constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 4 * kBlock + (2 * NV + 4) * (kBlock / 64));
   static bool configured = false;
   if (!configured) {
@@ -302,7 +311,7 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
     configured = true;
   }
   hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld,
-                     t_in, u_in, coef, v_out, u_out, t_out, part);
+                     t_in, u_in, coef, v_out, u_out, t_out, part, has_halo);
 }
 
 template <int NV>
@@ -316,11 +325,11 @@ template <int NV = kFusedMaxM - 1>
 struct FusedTable {
   static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
                     const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
-                    double *t_out, double *part) {
+                    double *t_out, double *part, int has_halo) {
     if (nv == NV)
-      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part);
+      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo);
     else
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part);
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo);
   }
   static void close(int nv, hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
                     const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
@@ -334,7 +343,7 @@ struct FusedTable {
 template <>
 struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const double *, int64_t, const double *,
-                    const double *, const double *, double *, double *, double *, double *) {}
+                    const double *, const double *, double *, double *, double *, double *, int) {}
   static void close(int, hipStream_t, const double *, int64_t, const double *, const double *, const double *,
                     double *, double *, int64_t, double *, int) {}
 };
@@ -348,9 +357,9 @@ int fused_parts(int rows, int cols) {
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *t_in, const double *u_in, const double *coef, double *v_out,
-                          double *u_out, double *t_out, double *part, int *nparts) {
+                          double *u_out, double *t_out, double *part, int *nparts, bool has_halo) {
   const FusedGeom g = fused_geom(rows, cols);
-  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part);
+  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo ? 1 : 0);
   *nparts = g.nstrips * g.nbands;
 }
 

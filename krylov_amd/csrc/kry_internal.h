@@ -125,9 +125,12 @@ int fused_parts(int rows, int cols);
 // already normalised and stored), orthogonalise t_in / ||u_in|| against the nv + 1
 // vectors with the coefficients coef[0..nv], store the new vector in u_out, A times
 // it in t_out, and the 2 nv + 4 partial sums (see k_arnoldi_fused) in part.
+// has_halo: the grid rows in front of the first and behind the last row are taken
+// from u_out[-cols..0) and u_out[rows*cols ..) (a neighbouring rank's rows) instead
+// of being treated as zero.
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *t_in, const double *u_in, const double *coef, double *v_out,
-                          double *u_out, double *t_out, double *part, int *nparts);
+                          double *u_out, double *t_out, double *part, int *nparts, bool has_halo);
 // The same without the operator application and the dots: only <u_out, u_out> in part.
 void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in,
                           const double *u_in, const double *coef, double *v_out, double *u_out, int64_t n,

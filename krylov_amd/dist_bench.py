@@ -101,7 +101,7 @@ def run(args, world, rank, local_rank, out_stream=None):
                              "alg_bytes_per_launch": per_launch,
                              "gbps": round(per_launch / (avg_ms * 1e-3) / 1e9, 1) if per_launch else None}
         roofline = None
-        timed = {n: k for n, k in kernels.items() if n in ("spmv_dots", "mgs_block_full", "mgs_block_part", "mgs_last")
+        timed = {n: k for n, k in kernels.items() if n in ("spmv_dots", "mgs_block_full", "mgs_block_part", "mgs_last", "arnoldi_fused")
                  and k["gbps"]}
         if timed:
             # the kernel family with the largest share of rank 0's kernel time

@@ -19,6 +19,8 @@ def rel(a, b):
     (2, "time_dependent", 12, 10, 8, 0),
     (3, "s_iso", 33, 20, 12, 0),
     (2, "prob1", 2, 5, 3, 0),
+    (3, "s_iso", 20, 300, 20, 0),  # rows wider than one strip of the one-sweep kernels
+    (3, "s_iso", 1, 40, 5, 0),     # one grid row per rank
 ])
 def test_slabs_match_single_rank(tmp_path, ctx, oracle, nranks, name, cx, cy, m, tdp):
     steps = 3
@@ -106,4 +108,6 @@ def test_bench_contract_two_ranks_shared_gpu(tmp_path):
         assert key in d
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64"
     assert d["collectives"] == "torch" and d["collectives_selfcheck_rel_err"] <= 1e-9
+    # the row blocks run the one-sweep Arnoldi kernels (8 of the 10 steps per cycle; the last is the closing sweep)
+    assert d["kernels"]["arnoldi_fused"]["launches"] == 2 * 7
     assert abs(d["value"] - 10 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
