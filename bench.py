@@ -209,7 +209,8 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("mesh") == n_side and tj.get("m") == m and tj.get("mgs_block") == K:
+                if (tj.get("mesh") == n_side and tj.get("m") == m and tj.get("mgs_block") == K
+                        and tj.get("one_sweep_from", -1) == dev.solver().get_one_sweep()):
                     traffic = tj.get("hbm_bytes_per_launch", {}).get(name)
             except Exception:
                 traffic = None

@@ -29,7 +29,7 @@
 // belong to its neighbours: the host first evaluates u_{i+1} on the block's
 // first and last row (k_arnoldi_close on those rows), exchanges them, and the
 // sweep reads the neighbours' rows from the halo of u_out instead of
-// recomputing them (has_halo).
+// recomputing them (u_halo).
 //
 // Requirements, checked by the host: 5-band operator whose couplings across
 // the ends of a grid row (band s in column 0, band n in the last column) are
@@ -78,9 +78,10 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
                                                            double *__restrict__ v_out,
-                                                           double *u_out,
+                                                           double *__restrict__ u_out,
                                                            double *__restrict__ t_out,
-                                                           double *__restrict__ part, int has_halo) {
+                                                           double *__restrict__ part,
+                                                           const double *__restrict__ u_halo) {
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
   double *keep = lds;                              // (NV + 1) x kBlock: v_k and v_NV of the previous row
@@ -125,6 +126,12 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       uin_n = __builtin_nontemporal_load(&u_in[idx]);
 #pragma unroll
       for (int k = 0; k < NV; k++) vn[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idx]);
+    } else if (u_halo != nullptr && !rowvalid && c >= 0 && c < P) {
+      // a neighbouring rank's boundary row of the new vector itself (zeros beyond the
+      // mesh); u_halo is u_out, read only outside the rows this kernel writes.  The read
+      // sits with the other requests of the row: a load inside the arithmetic below would
+      // make the compiler drain all outstanding requests there.
+      uin_n = u_halo[idx];
     }
     // operator coefficients of row rr - 1, whose application completes one round later
     if (rr - 1 >= rs && rr - 1 < re && colowned) {
@@ -158,9 +165,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 #pragma unroll
       for (int k = 0; k < NV; k++) u = u - lane_value(hpack, k) * vk[k];
       u = u - lane_value(hpack, NV) * vi;
-    } else if (has_halo && !rowvalid && c >= 0 && c < P) {
-      // the neighbouring rank's boundary row of the new vector (zeros beyond the mesh)
-      u = u_out[idx];
+    } else {
+      u = uin;  // zero, or a neighbouring rank's row of the new vector
     }
     if (rr >= rs && rr < re && colowned) {
       if (v_out) v_out[idx] = vi;
@@ -302,7 +308,7 @@ FusedGeom fused_geom(int rows, int P) {
 template <int NV>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
                     const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
-                    double *t_out, double *part, int has_halo) {
+                    double *t_out, double *part, const double *u_halo) {
   constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 4 * kBlock + (2 * NV + 4) * (kBlock / 64));
   static bool configured = false;
   if (!configured) {
@@ -311,7 +317,7 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
     configured = true;
   }
   hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld,
-                     t_in, u_in, coef, v_out, u_out, t_out, part, has_halo);
+                     t_in, u_in, coef, v_out, u_out, t_out, part, u_halo);
 }
 
 template <int NV>
@@ -325,11 +331,11 @@ template <int NV = kFusedMaxM - 1>
 struct FusedTable {
   static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
                     const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
-                    double *t_out, double *part, int has_halo) {
+                    double *t_out, double *part, const double *u_halo) {
     if (nv == NV)
-      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo);
+      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, u_halo);
     else
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo);
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, u_halo);
   }
   static void close(int nv, hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
                     const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
@@ -343,7 +349,7 @@ struct FusedTable {
 template <>
 struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const double *, int64_t, const double *,
-                    const double *, const double *, double *, double *, double *, double *, int) {}
+                    const double *, const double *, double *, double *, double *, double *, const double *) {}
   static void close(int, hipStream_t, const double *, int64_t, const double *, const double *, const double *,
                     double *, double *, int64_t, double *, int) {}
 };
@@ -359,7 +365,7 @@ void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Band
                           const double *t_in, const double *u_in, const double *coef, double *v_out,
                           double *u_out, double *t_out, double *part, int *nparts, bool has_halo) {
   const FusedGeom g = fused_geom(rows, cols);
-  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo ? 1 : 0);
+  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo ? u_out : nullptr);
   *nparts = g.nstrips * g.nbands;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -93,6 +94,22 @@ int main(int argc, char **argv) {
   CHECK(hipMalloc((void **)&out, sizeof(double) * 65536));
   double *Wr;
   CHECK(hipMalloc((void **)&Wr, sizeof(double) * ld * 3)); CHECK(hipMemset(Wr, 0, sizeof(double) * ld * 3));
+  if (argc > 2 && !strcmp(argv[2], "calib")) {
+    // Known byte counts for calibrating the memory-side counters on 8-byte-per-lane accesses:
+    // every launch touches `cols` columns of every row in each of its streams.
+    const int Wc = 249, nstrips = 33;
+    long cols = 0;
+    for (int s = 0; s < nstrips; s++)
+      for (int t = 0; t <= Wc + 1; t++) { const int c = s * Wc - 1 + t; if (c >= 0 && c < P) cols++; }
+    const double per_stream = 8.0 * (double)rows * (double)cols;
+    printf("CALIB strip<16, 1, 256, true, 0, false> read_bytes %.0f write_bytes 0\n", 16 * per_stream);
+    printf("CALIB strip<16, 1, 256, true, 3, false> read_bytes %.0f write_bytes %.0f\n", 16 * per_stream, 3 * per_stream);
+    printf("CALIB strip<16, 1, 256, true, 3, true> read_bytes %.0f write_bytes %.0f\n", 16 * per_stream, 3 * per_stream);
+    run<16, 1, 256, true>("8 B/lane, reads only", V, ld, rows, P, 1024, out);
+    run<16, 1, 256, true, 3>("8 B/lane, 3 write streams", V, ld, rows, P, 1024, out, Wr);
+    run<16, 1, 256, true, 3, true>("8 B/lane, 3 NT write streams", V, ld, rows, P, 1024, out, Wr);
+    return 0;
+  }
   for (int wgs : {1024}) {
     run<16, 2, 256, true>("16 B/lane, reads only", V, ld, rows, P, wgs, out);
     run<16, 2, 256, true, 1>("16 B/lane, 1 write stream", V, ld, rows, P, wgs, out, Wr);
