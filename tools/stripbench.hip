@@ -11,7 +11,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // VEC = 1: 8 bytes per lane, strip of BLK - 2 owned columns starting one column early (unaligned);
 // VEC = 2: 16 bytes per lane, strip of 2 * BLK columns starting at an even column.
-template <int K, int VEC, int BLK, bool BARRIER, int NW = 0, bool NT = false>
+template <int K, int VEC, int BLK, bool BARRIER, int NW = 0, bool NT = false, int MODE = 0>
 __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
                                              int R, double *__restrict__ out, double *__restrict__ Wr = nullptr) {
   __shared__ double ring[BLK * VEC];
@@ -22,8 +22,11 @@ __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long 
   const bool ok = c >= 0 && c + VEC <= P && (VEC == 1 ? t <= W + 1 : 2 * t < W);
   const int rs = band * R, re = rs + R < rows ? rs + R : rows;
   double acc[K];
+  double held = 0.0;
+  double hold8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < K; k++) acc[k] = 0.0;
+#pragma unroll 8
   for (int rr = rs; rr < re; rr++) {
     const long idx = (long)rr * P + c;
     double s = 0.0;
@@ -42,7 +45,22 @@ __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long 
         for (int k = 0; k < K; k++) { acc[k] += v[k].x + v[k].y; s += v[k].x; }
       }
     }
-    if (NW > 0 && ok) {
+    if (MODE == 3) {
+      hold8[(rr - rs) & 7] = s;
+      if (((rr - rs) & 7) == 7 && ok) {
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const long idx8 = (long)(rr - 7 + j) * P + c;
+            if (NT) __builtin_nontemporal_store(hold8[j] + k, &Wr[k * ld + idx8]); else Wr[k * ld + idx8] = hold8[j] + k;
+          }
+      }
+    }
+    if (MODE == 1) s = (double)rr;
+    if (MODE == 2) { const double cur = s; s = held; held = cur; }
+    if (NW > 0 && ok && MODE != 3 && (MODE != 2 || rr > rs)) {
+      const long idx = (long)(MODE == 2 ? rr - 1 : rr) * P + c;
 #pragma unroll
       for (int k = 0; k < NW; k++) {
         if (VEC == 1) { if (NT) __builtin_nontemporal_store(s + k, &Wr[k * ld + idx]); else Wr[k * ld + idx] = s + k; }
@@ -62,7 +80,7 @@ __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long 
   if (s == 12345.678) out[blockIdx.x] = s;
 }
 
-template <int K, int VEC, int BLK, bool BARRIER, int NW = 0, bool NT = false>
+template <int K, int VEC, int BLK, bool BARRIER, int NW = 0, bool NT = false, int MODE = 0>
 void run(const char *name, const double *V, long ld, int rows, int P, int wgs_target, double *out, double *Wr = nullptr) {
   const int Wmax = VEC == 1 ? BLK - 2 : 2 * BLK;
   const int nstrips = (P + Wmax - 1) / Wmax;
@@ -73,15 +91,15 @@ void run(const char *name, const double *V, long ld, int rows, int P, int wgs_ta
   const int R = (rows + nb - 1) / nb;
   const int nbands = (rows + R - 1) / R;
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  for (int r = 0; r < 2; r++) hipLaunchKernelGGL((strip<K, VEC, BLK, BARRIER, NW, NT>), dim3(nstrips * nbands), dim3(BLK), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
+  for (int r = 0; r < 2; r++) hipLaunchKernelGGL((strip<K, VEC, BLK, BARRIER, NW, NT, MODE>), dim3(nstrips * nbands), dim3(BLK), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
   CHECK(hipDeviceSynchronize());
   const int reps = 5;
   CHECK(hipEventRecord(e0));
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((strip<K, VEC, BLK, BARRIER, NW, NT>), dim3(nstrips * nbands), dim3(BLK), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((strip<K, VEC, BLK, BARRIER, NW, NT, MODE>), dim3(nstrips * nbands), dim3(BLK), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipGetLastError());
   const double bytes = 8.0 * (K + NW) * (double)rows * P;
-  printf("%-44s K=%2d wgs %5d (strips %3d x bands %3d, W %3d, R %4d) %8.1f us %7.1f GB/s\n", name, K, nstrips * nbands, nstrips,
+  printf("%-64s K=%2d wgs %5d (strips %3d x bands %3d, W %3d, R %4d) %8.1f us %7.1f GB/s\n", name, K, nstrips * nbands, nstrips,
          nbands, W, R, ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9);
 }
 
@@ -111,11 +129,24 @@ int main(int argc, char **argv) {
     return 0;
   }
   for (int wgs : {1024}) {
+    run<16, 1, 256, true>("8 B/lane, reads only", V, ld, rows, P, wgs, out);
+    run<16, 1, 256, true, 1>("8 B/lane, 1 write stream", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 1, true>("8 B/lane, 1 NT write stream", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 3, true>("8 B/lane, 3 NT write streams", V, ld, rows, P, wgs, out, Wr);
     run<16, 2, 256, true>("16 B/lane, reads only", V, ld, rows, P, wgs, out);
     run<16, 2, 256, true, 1>("16 B/lane, 1 write stream", V, ld, rows, P, wgs, out, Wr);
     run<16, 2, 256, true, 1, true>("16 B/lane, 1 NT write stream", V, ld, rows, P, wgs, out, Wr);
     run<16, 2, 256, true, 3, true>("16 B/lane, 3 NT write streams", V, ld, rows, P, wgs, out, Wr);
+    run<40, 1, 256, true, 3, true>("8 B/lane, 3 NT write streams", V, ld, rows, P, wgs, out, Wr);
     run<40, 2, 256, true, 3, true>("16 B/lane, 3 NT write streams", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 1, true, 1>("8 B/lane, 1 NT write stream, value independent of the loads", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 1, true, 2>("8 B/lane, 1 NT write stream, stored one row late", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 3, true, 1>("8 B/lane, 3 NT write streams, value independent of the loads", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 1, true, 3>("8 B/lane, 1 NT write stream, 8 rows stored together", V, ld, rows, P, wgs, out, Wr);
+    run<16, 1, 256, true, 3, true, 3>("8 B/lane, 3 NT write streams, 8 rows stored together", V, ld, rows, P, wgs, out, Wr);
+    run<40, 1, 256, true, 3, true, 3>("8 B/lane, 3 NT write streams, 8 rows stored together", V, ld, rows, P, wgs, out, Wr);
+    run<48, 1, 256, true>("8 B/lane, reads only", V, ld, rows, P, wgs, out);
+    run<48, 2, 256, true>("16 B/lane, reads only", V, ld, rows, P, wgs, out);
   }
   return 0;
 }
