@@ -187,8 +187,11 @@ int kry_gmres_get_mgs_block(const kry_gmres *g);
  * Gram matrix as above.  Same Krylov space and Hessenberg matrix up to rounding.
  * Available for a 5-band operator without couplings across the ends of a grid
  * row (on several ranks: the row-block decomposition of kry_ie_create_slab),
- * plain mode (no preconditioner, not KRY_GMRES_EXTENDED) and 3 <= m <= 50;
- * otherwise, and for kry_gmres_add_arnoldi, the chain is used.
+ * no preconditioner and 3 <= m <= 50; otherwise, and for kry_gmres_add_arnoldi,
+ * the chain is used.  With KRY_GMRES_EXTENDED the residual monitor sees column i
+ * one sweep later than with the chain (H(i+1,i) is the norm the next sweep's sums
+ * deliver): the iterate and the reported iteration count are the same, one sweep
+ * more has run when the solver stops.
  * first_step < 0 switches the sweeps off; values above min(m - 2, 31) are clamped.
  * Default 2 (environment override: KRY_FUSED_FROM).  The getter returns -1 when
  * the sweeps are off or unavailable for this solver. */

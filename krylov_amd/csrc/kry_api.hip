@@ -211,7 +211,7 @@ struct kry_gmres {
   double *R = nullptr;        // (m+1) x m rotated Hessenberg | cs (m) | sn (m) | gv (m+1)
   int last_iters = 0, last_cycles = 0, last_converged = 0;
   double last_relres = 0.0;
-  // one-sweep Arnoldi steps (plain mode, stencil operator, one rank): first step that
+  // one-sweep Arnoldi steps (no preconditioner, grid stencil operator): first step that
   // uses them (< 0: never), the un-normalised new vector (ping-pong), the second
   // operator-result buffer (the first is w), partial sums, totals, coefficients
   int fused_from = -1;
@@ -742,7 +742,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
     if (st == KRY_OK) st = dev_alloc(&g->ud, g->ld);
   }
-  if (st == KRY_OK && !(flags & (KRY_GMRES_EXTENDED | KRY_GMRES_TDP)) &&
+  if (st == KRY_OK && !(flags & KRY_GMRES_TDP) &&
       m <= kFusedMaxM && m >= 3) {
     int from = 2;
     if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
@@ -824,7 +824,7 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
     return KRY_OK;
   }
   if (!g->fu[0])
-    return fail(KRY_ERR_STATE, "one-sweep steps need plain mode (no preconditioner, not extended) and 3 <= num_iters <= %d", kFusedMaxM);
+    return fail(KRY_ERR_STATE, "one-sweep steps need a solver without preconditioner and 3 <= num_iters <= %d", kFusedMaxM);
   g->fused_from = first_step > fused_from_max(g->m) ? fused_from_max(g->m) : first_step;
   return KRY_OK;
 }
@@ -982,6 +982,9 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   return launch_ok("add_arnoldi");
 }
 
+static bool fused_usable(const kry_gmres *g, const kry_op *op);
+static int fused_steps_async(kry_gmres *g, kry_op *op);
+
 // Restarted GMRES(m) with Givens rotations and a residual monitor on the
 // device.  One host round trip per cycle (to decide about a restart), none
 // inside a cycle: after convergence the remaining kernels of the cycle return
@@ -1020,11 +1023,13 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       launch_ext_begin(st, g->beta, g->ext, gv, m, cycle == 0, g->rtol);
     }
     HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(m + 1) * m, st));
-    for (int j = 0; j < m; j++) {
+    const int chain_steps = fused_usable(g, op) ? g->fused_from : m;
+    for (int j = 0; j < chain_steps; j++) {
       KCHK(arnoldi_async(g, op));
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
       launch_givens(st, g->H, m, j, R, cs, sn, gv, g->ext);
     }
+    if (chain_steps < m) KCHK(fused_steps_async(g, op));
     {
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
       launch_ext_solve(st, R, gv, m, g->ext, g->y);
@@ -1073,7 +1078,15 @@ static int fused_totals(kry_gmres *g, int nq, int np) {
 
 // Steps fused_from .. m-1 of a cycle, one sweep over the basis each (kry_fused.hip).
 // On entry the basis holds v_0..v_from; on return v_0..v_m and H are complete.
+// In the restarted solver the Givens update of column i follows as soon as H(i+1,i) is
+// known, which is one sweep later than with the chain: when the residual monitor raises
+// the stop flag, one sweep beyond the last column used has already run (its results
+// are simply not used), and everything after it returns at once.
 static int fused_steps_async(kry_gmres *g, kry_op *op) {
+  const bool ext = (g->flags & KRY_GMRES_EXTENDED) && g->ext;
+  LaunchPredicate pred(ext ? &g->ext->stop : nullptr);
+  double *R = g->R, *rot_c = ext ? R + (int64_t)(g->m + 1) * g->m : nullptr, *rot_s = ext ? rot_c + g->m : nullptr,
+         *gv = ext ? rot_s + g->m : nullptr;
   hipStream_t st = g->ctx->stream;
   const int m = g->m, i0 = g->fused_from;
   const int64_t n = g->n;
@@ -1092,6 +1105,10 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   for (int i = i0; i < m; i++) {
     const bool boot = i == i0;
     launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef);
+    if (ext && !boot) {
+      ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+      launch_givens(st, g->H, m, i - 1, R, rot_c, rot_s, gv, g->ext);
+    }
     const double *u_in = boot ? basis(g, i) : g->fu[i & 1];
     double *v_out = boot ? nullptr : basis(g, i);
     double *u_out = g->fu[(i + 1) & 1];
@@ -1126,6 +1143,10 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   {
     ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
     launch_scale_from(st, g->fu[m & 1], basis(g, m), pin, np, n, g->H + (int64_t)m * m + (m - 1));
+  }
+  if (ext) {
+    ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
+    launch_givens(st, g->H, m, m - 1, R, rot_c, rot_s, gv, g->ext);
   }
   g->nvec = m + 1;
   return launch_ok("one-sweep Arnoldi steps");

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
                                                            double *__restrict__ u_out,
                                                            double *__restrict__ t_out,
                                                            double *__restrict__ part,
-                                                           const double *__restrict__ u_halo) {
+                                                           const double *__restrict__ u_halo,
+                                                           const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
   double *keep = lds;                              // (NV + 1) x kBlock: v_k and v_NV of the previous row
@@ -209,7 +211,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restri
                                                            const double *__restrict__ coef,
                                                            double *__restrict__ v_out,
                                                            double *__restrict__ u_out, int64_t n,
-                                                           double *__restrict__ part) {
+                                                           double *__restrict__ part,
+                                                           const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   __shared__ double s[kBlock / 64];
   double h[NV + 1];
 #pragma unroll
@@ -237,7 +241,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restri
 
 // tot[q] = sum of part[q * np .. q * np + np): one workgroup per quantity.
 __global__ __launch_bounds__(kBlock) void k_reduce_parts_wide(const double *__restrict__ part, int np,
-                                                               double *__restrict__ tot) {
+                                                               double *__restrict__ tot,
+                                                               const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   __shared__ double s[kBlock / 64];
   const int q = blockIdx.x;
   double a = 0.0;
@@ -254,7 +260,9 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts_wide(const double *__re
 __global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ tot, int i, int boot,
                                                       double *__restrict__ G, int gld,
                                                       double *__restrict__ H, int m,
-                                                      double *__restrict__ coef) {
+                                                      double *__restrict__ coef,
+                                                      const int *__restrict__ stop) {
+  if (stopped(stop)) return;
   __shared__ double gs[kFusedMaxM * kFusedMaxM];
   const int lane = threadIdx.x;
   const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
@@ -317,14 +325,14 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
     configured = true;
   }
   hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld,
-                     t_in, u_in, coef, v_out, u_out, t_out, part, u_halo);
+                     t_in, u_in, coef, v_out, u_out, t_out, part, u_halo, launch_predicate_current());
 }
 
 template <int NV>
 void launch_close_t(hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
                     const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
   hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(grid), dim3(kBlock), 0, st, V, ld, t_in, u_in, coef, v_out, u_out,
-                     n, part);
+                     n, part, launch_predicate_current());
 }
 
 template <int NV = kFusedMaxM - 1>
@@ -379,12 +387,13 @@ void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, c
 }
 
 void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot) {
-  hipLaunchKernelGGL(k_reduce_parts_wide, dim3(nq), dim3(kBlock), 0, st, part, np, tot);
+  hipLaunchKernelGGL(k_reduce_parts_wide, dim3(nq), dim3(kBlock), 0, st, part, np, tot, launch_predicate_current());
 }
 
 void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
                          int m, double *coef) {
-  hipLaunchKernelGGL(k_fused_coeffs, dim3(1), dim3(64), 0, st, tot, i, boot ? 1 : 0, G, gld, H, m, coef);
+  hipLaunchKernelGGL(k_fused_coeffs, dim3(1), dim3(64), 0, st, tot, i, boot ? 1 : 0, G, gld, H, m, coef,
+                     launch_predicate_current());
 }
 
 }  // namespace kry

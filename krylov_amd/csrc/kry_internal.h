@@ -40,6 +40,8 @@ struct ExtState {
 // calling thread (operator apply, Gram-Schmidt sweeps, normalisation, line
 // solves, partial-sum collapse) receive `stop` and return at once when *stop
 // is non-zero on the device.
+const int *launch_predicate_current();  // the flag of the innermost live LaunchPredicate of this thread, or nullptr
+
 class LaunchPredicate {
  public:
   explicit LaunchPredicate(const int *stop);

@@ -26,6 +26,7 @@ static thread_local const int *t_stop = nullptr;
 
 LaunchPredicate::LaunchPredicate(const int *stop) : saved_(t_stop) { t_stop = stop; }
 LaunchPredicate::~LaunchPredicate() { t_stop = saved_; }
+const int *launch_predicate_current() { return t_stop; }
 
 int grid_for(int64_t items) {
   int64_t b = (items + kBlock - 1) / kBlock;

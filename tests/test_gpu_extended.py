@@ -16,7 +16,13 @@ def rel(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("block", [1, 4, 8, 16, 32])
+# ("chain", K): K Gram-Schmidt links per sweep, basis read twice per step; ("sweep", s):
+# one-sweep Arnoldi steps from step s on (the residual monitor then runs one sweep behind)
+VARIANTS = [("chain", 1), ("chain", 4), ("chain", 8), ("chain", 16), ("chain", 32), ("sweep", 0), ("sweep", 2),
+            ("sweep", 6)]
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "%s%d" % v)
 @pytest.mark.parametrize("name,args,m,tdp,rtol", [
     ("prob1", (38, 18), 10, False, 1e-12),
     ("prob1", (38, 18), 30, False, 1e-12),
@@ -26,10 +32,18 @@ def rel(a, b):
     ("time_dependent", (12, 10), 8, False, 1e-12),
     ("prob1", (37, 17), 10, False, 1e-12),  # odd row length: scalar operator kernel
 ])
-def test_solve_matches_cpu_statement(ctx, oracle, name, args, m, tdp, rtol, block):
+def test_solve_matches_cpu_statement(ctx, oracle, name, args, m, tdp, rtol, variant):
     prob = getattr(problems, name)(*args)
     ref = oracle.ImplicitEuler(**prob, m=m, tdp=tdp)
-    dev = host.ImplicitEuler(ctx, **prob, m=m, tdp=tdp, extended=(rtol, 60), mgs_block=block)
+    if variant[0] == "sweep":
+        if tdp:
+            pytest.skip("the preconditioned solver keeps the chain")
+        kw = {"one_sweep": variant[1]}
+    else:
+        kw = {"one_sweep": -1, "mgs_block": variant[1]}
+    dev = host.ImplicitEuler(ctx, **prob, m=m, tdp=tdp, extended=(rtol, 60), **kw)
+    if variant[0] == "sweep":
+        assert dev.solver().get_one_sweep() == min(variant[1], m - 2)
     ref.assemble_system(0.25)
     dev.assemble_system(0.25)
     b = ref.sol_vec()
