@@ -171,8 +171,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       u = uin;  // zero, or a neighbouring rank's row of the new vector
     }
     if (rr >= rs && rr < re && colowned) {
-      if (v_out) v_out[idx] = vi;
-      u_out[idx] = u;
+      if (v_out) __builtin_nontemporal_store(vi, &v_out[idx]);
+      __builtin_nontemporal_store(u, &u_out[idx]);
 #pragma unroll
       for (int k = 0; k < NV; k++) acc[NV + 2 + k] = fma(vk[k], u, acc[NV + 2 + k]);
       acc[2 * NV + 2] = fma(vi, u, acc[2 * NV + 2]);
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restri
 #pragma unroll
     for (int k = 0; k < NV; k++) u = u - h[k] * vk[k];
     u = u - h[NV] * vi;
-    if (v_out) v_out[i] = vi;
-    u_out[i] = u;
+    if (v_out) __builtin_nontemporal_store(vi, &v_out[i]);
+    __builtin_nontemporal_store(u, &u_out[i]);
     a = fma(u, u, a);
   }
   const double tot = block_sum(a, s);
