@@ -215,9 +215,12 @@ struct kry_gmres {
   // uses them (< 0: never), the un-normalised new vector (ping-pong), the second
   // operator-result buffer (the first is w), partial sums, totals, coefficients
   int fused_from = -1;
-  double *fu[2] = {nullptr, nullptr};
   double *fw = nullptr;
   double *fparts = nullptr, *ftot = nullptr, *fcoef = nullptr;
+  // the sweeps leave their vectors un-normalised: slot k of V holds fsigma[k] * v_k
+  // (fsigma[k] = 1 for vectors stored by the chain); valid while scaled is set
+  double *fsigma = nullptr;
+  bool scaled = false;
 };
 
 struct kry_ie {
@@ -747,9 +750,8 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     int from = 2;
     if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
     if (from > fused_from_max(m)) from = fused_from_max(m);
-    st = dev_alloc(&g->fu[0], g->ld);
-    if (st == KRY_OK) st = dev_alloc(&g->fu[1], g->ld);
-    if (st == KRY_OK) st = dev_alloc(&g->fw, g->ld);
+    st = dev_alloc(&g->fw, g->ld);
+    if (st == KRY_OK) st = dev_alloc(&g->fsigma, kFusedCoef);
     if (st == KRY_OK) st = dev_alloc(&g->fparts, (int64_t)kFusedRed * kMaxParts);
     if (st == KRY_OK) st = dev_alloc(&g->ftot, kFusedRed);
     if (st == KRY_OK) st = dev_alloc(&g->fcoef, kFusedCoef);
@@ -766,14 +768,13 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
   (void)hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)g->ld, s);
   if (g->z) (void)hipMemsetAsync(g->z, 0, sizeof(double) * (size_t)g->ld, s);
-  for (double *p : {g->fu[0], g->fu[1], g->fw})
-    if (p) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)g->ld, s);
+  if (g->fw) (void)hipMemsetAsync(g->fw, 0, sizeof(double) * (size_t)g->ld, s);
+  if (g->fsigma) launch_fill(s, g->fsigma, 1.0, kFusedCoef);
   // work vectors are addressed at their first owned entry from here on
   g->w += g->halo;
   g->vars += g->halo;
   if (g->z) g->z += g->halo;
-  for (double **p : {&g->fu[0], &g->fu[1], &g->fw})
-    if (*p) *p += g->halo;
+  if (g->fw) g->fw += g->halo;
   g->offset_applied = true;
   launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
   st = launch_ok("kry_gmres_create");
@@ -793,8 +794,8 @@ void kry_gmres_destroy(kry_gmres *g) {
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
                     g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
-                    g->dd, g->ud, g->R, g->G, g->fu[0] ? g->fu[0] - off : nullptr, g->fu[1] ? g->fu[1] - off : nullptr,
-                    g->fw ? g->fw - off : nullptr, g->fparts, g->ftot, g->fcoef};
+                    g->dd, g->ud, g->R, g->G, g->fw ? g->fw - off : nullptr, g->fparts, g->ftot, g->fcoef,
+                    g->fsigma};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
   if (g->ext_h) (void)hipHostFree(g->ext_h);
@@ -823,13 +824,13 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
     g->fused_from = -1;
     return KRY_OK;
   }
-  if (!g->fu[0])
+  if (!g->fw)
     return fail(KRY_ERR_STATE, "one-sweep steps need a solver without preconditioner and 3 <= num_iters <= %d", kFusedMaxM);
   g->fused_from = first_step > fused_from_max(g->m) ? fused_from_max(g->m) : first_step;
   return KRY_OK;
 }
 
-int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fu[0] ? g->fused_from : -1; }
+int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fw ? g->fused_from : -1; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
@@ -916,6 +917,7 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
     launch_scale_from(st, b_dev, basis(g, 0), pin, np, g->n, g->beta);
   }
   g->nvec = 1;
+  g->scaled = false;
   return launch_ok("initial_subspace");
 }
 
@@ -1017,6 +1019,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       KCHK(finish_parts(g, &pin, 1, &np));
       launch_scale_from(st, g->w, basis(g, 0), pin, np, n, g->beta);
       g->nvec = 1;
+      g->scaled = false;
     }
     {
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
@@ -1048,7 +1051,8 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       launch_add(st, g->vars, g->w, n);
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
-      launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true);
+      launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true,
+                     g->scaled ? g->fsigma : nullptr);
     }
     KCHK(launch_ok("extended solve"));
     HIPCHK(hipMemcpyAsync(g->ext_h, g->ext, sizeof(ExtState), hipMemcpyDeviceToHost, st));
@@ -1104,50 +1108,39 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   KCHK(fused_totals(g, 2 * (i0 + 1) - 1, np));
   for (int i = i0; i < m; i++) {
     const bool boot = i == i0;
-    launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef);
+    launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef, g->fsigma);
     if (ext && !boot) {
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
       launch_givens(st, g->H, m, i - 1, R, rot_c, rot_s, gv, g->ext);
     }
-    const double *u_in = boot ? basis(g, i) : g->fu[i & 1];
-    double *v_out = boot ? nullptr : basis(g, i);
-    double *u_out = g->fu[(i + 1) & 1];
     if (i < m - 1) {
       if (ranks) {
         // the new vector on this rank's first and last row, for the neighbours
         ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
         for (int64_t off : {(int64_t)0, n - P}) {
-          launch_arnoldi_close(st, i, basis(g, 0) + off, g->ld, tb[i & 1] + off, u_in + off, g->fcoef, nullptr,
-                               u_out + off, P, g->fparts, &np);
+          launch_arnoldi_close(st, i, basis(g, 0) + off, g->ld, tb[i & 1] + off, g->fcoef, P, g->fparts, &np);
           if (n == P) break;
         }
-        KCHK(comm_halo(g->ctx, u_out, P, n));
+        KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
       }
       {
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
-        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out,
-                             u_out, tb[(i + 1) & 1], g->fparts, &np, ranks);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, tb[i & 1], g->fcoef, tb[(i + 1) & 1],
+                             g->fparts, &np, ranks);
       }
       KCHK(fused_totals(g, 2 * i + 4, np));
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-      launch_arnoldi_close(st, i, basis(g, 0), g->ld, tb[i & 1], u_in, g->fcoef, v_out, u_out, n, g->fparts, &np);
+      launch_arnoldi_close(st, i, basis(g, 0), g->ld, tb[i & 1], g->fcoef, n, g->fparts, &np);
     }
   }
-  const double *pin = g->fparts;
-  if (ranks) {
-    KCHK(fused_totals(g, 1, np));
-    pin = g->ftot;
-    np = 1;
-  }
-  {
-    ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
-    launch_scale_from(st, g->fu[m & 1], basis(g, m), pin, np, n, g->H + (int64_t)m * m + (m - 1));
-  }
+  KCHK(fused_totals(g, 1, np));
+  launch_fused_finish(st, g->ftot, m, g->H, g->fsigma);
   if (ext) {
     ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
     launch_givens(st, g->H, m, m - 1, R, rot_c, rot_s, gv, g->ext);
   }
+  g->scaled = true;
   g->nvec = m + 1;
   return launch_ok("one-sweep Arnoldi steps");
 }
@@ -1170,7 +1163,8 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
-    launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n);
+    launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n, nullptr, false,
+                   g->scaled ? g->fsigma : nullptr);
   }
   if ((g->flags & KRY_GMRES_TDP) && (g->flags & KRY_GMRES_FIXED_PRECOND)) {
     ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
@@ -1271,7 +1265,14 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
   if (!g || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
   if (i < 0 || i >= g->nvec) return fail(KRY_ERR_INVALID, "subspace vector %d does not exist (%d vectors)", i, g->nvec);
   HIPCHK(hipSetDevice(g->ctx->device));
-  HIPCHK(hipMemcpyAsync(out_host, basis(g, i), sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
+  const double *src = basis(g, i);
+  if (g->scaled) {
+    // the one-sweep steps keep their vectors un-normalised: v_i = slot_i / sigma_i
+    launch_unscale(g->ctx->stream, src, g->fsigma, i, g->fw, g->n);
+    KCHK(launch_ok("kry_gmres_subspace_vector"));
+    src = g->fw;
+  }
+  HIPCHK(hipMemcpyAsync(out_host, src, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
   HIPCHK(hipStreamSynchronize(g->ctx->stream));
   return KRY_OK;
 }
@@ -1337,16 +1338,16 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
     launches[KRY_K_SPMV] += 1;
     for (int i = i0; i < m - 1; i++) {
-      // read: t, u, v_0..v_{i-1}, operator; written: v_i (not in the first sweep), u, t
-      bytes[KRY_K_FUSED] += (2.0 + i) * N + opb + (i == i0 ? 2.0 : 3.0) * N;
+      // read: t, the i + 1 stored vectors, operator; written: the new vector and t
+      bytes[KRY_K_FUSED] += (2.0 + i) * N + opb + 2.0 * N;
       launches[KRY_K_FUSED] += 1;
     }
-    bytes[KRY_K_MGS_LAST] += (2.0 + (m - 1)) * N + 2.0 * N;  // closing sweep: t, u, basis read; v, u written
+    bytes[KRY_K_MGS_LAST] += (1.0 + m) * N + N;  // closing sweep: t and the m stored vectors read; the new one written
     launches[KRY_K_MGS_LAST] += 1;
   }
-  // one normalisation per chain step (one in all after the one-sweep steps) + ||b|| and v_0 = b/||b||
-  bytes[KRY_K_NORMALIZE] = 2.0 * N * (fused ? chain_steps + 1 : m) + 3.0 * N;
-  launches[KRY_K_NORMALIZE] = (fused ? chain_steps + 1 : m) + 2;
+  // one normalisation per chain step (none after the one-sweep steps) + ||b|| and v_0 = b/||b||
+  bytes[KRY_K_NORMALIZE] = 2.0 * N * chain_steps + 3.0 * N;
+  launches[KRY_K_NORMALIZE] = chain_steps + 2;
   bytes[KRY_K_COMBINE] = (m + 1) * N;
   launches[KRY_K_COMBINE] = 1;
   if (g->flags & KRY_GMRES_TDP) {

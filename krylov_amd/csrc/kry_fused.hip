@@ -2,21 +2,25 @@
 //
 // The plain chain of include/solver.hpp:196-211 reads the basis twice per
 // step: once for the dot products <w, v_k>, once for w -= h_k v_k.  The sweep
-// below reads it once.  Per step i it consumes the un-normalised new vector
-// u_i and t_i = A u_i that the previous sweep left behind, and in ONE pass over
-// the grid
-//     v_i     = u_i / ||u_i||                       (stored as basis vector i)
-//     w       = t_i / ||u_i||                       (= A v_i up to rounding)
-//     u_{i+1} = w - h_0 v_0 - ... - h_i v_i         (modified Gram-Schmidt order)
-//     t_{i+1} = A u_{i+1}
-// and accumulates <t_{i+1}, v_k>, <t_{i+1}, u_{i+1}>, <v_k, u_{i+1}> (k <= i)
-// and <u_{i+1}, u_{i+1}>.  From those sums the next step's coefficients follow
-// without touching a vector again (k_fused_coeffs): with n = ||u_{i+1}||,
-//     <A v_{i+1}, v_k> = <t, v_k> / n,   <A v_{i+1}, v_{i+1}> = <t, u> / n^2,
-//     <v_k, v_{i+1}>   = <v_k, u> / n    (the carried Gram column),
+// below reads it once.  The vectors it produces stay UN-NORMALISED in the basis
+// array: slot k holds s_k = sigma_k v_k with sigma_k = ||s_k|| kept in a small
+// array (sigma_k = 1 for the vectors the chain stored).  Per step i the sweep
+// consumes s_0..s_i and t_i = A s_i that the previous sweep left behind, and in
+// ONE pass over the grid
+//     w       = t_i / sigma_i                          (= A v_i up to rounding)
+//     s_{i+1} = w - c_0 s_0 - ... - c_i s_i,  c_k = h_k / sigma_k
+//                                              (modified Gram-Schmidt order)
+//     t_{i+1} = A s_{i+1}
+// and accumulates <t_{i+1}, s_k>, <s_k, s_{i+1}> (k <= i), <t_{i+1}, s_{i+1}>
+// and <s_{i+1}, s_{i+1}>.  From those sums the next step's coefficients follow
+// without touching a vector again (k_fused_coeffs): with n = sigma_{i+1},
+//     <A v_{i+1}, v_k> = <t, s_k> / (sigma_k n),   <A v_{i+1}, v_{i+1}> = <t, s> / n^2,
+//     <v_k, v_{i+1}>   = <s_k, s> / (sigma_k n)    (the carried Gram column),
 // and the modified-Gram-Schmidt coefficients are recovered from the dots of the
 // un-updated w and the Gram matrix, h_k = d_k - sum_{a<k} h_a g_ak, exactly as
-// the blocked sweeps do within one group.
+// the blocked sweeps do within one group.  Whoever needs v_k divides by sigma_k
+// (kry_gmres_subspace_vector), or divides the coefficient that multiplies it
+// (the final combination x = sum y_k v_k).
 //
 // t = A u needs u at the four neighbours, so the sweep is tiled in two
 // dimensions: a workgroup owns a strip of at most 254 columns (thread = column,
@@ -67,17 +71,17 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// NV: basis vectors already normalised (v_0..v_{NV-1}, read from V); the vector
-// being normalised in this sweep is number NV.
-// part layout (q * gridDim.x + workgroup): q <= NV: <t, v_q>;  NV+1: <t, u>;
-// NV+2+a, a <= NV: <v_a, u>;  2 NV + 3: <u, u>.
+// NV: step number; s_0..s_{NV-1} are read from V, s_NV from u_in (it is slot NV of the
+// same array; a separate argument keeps the register arrays NV long).
+// u: the new vector s_{NV+1}.
+// part layout (q * gridDim.x + workgroup): q <= NV: <t, s_q>;  NV+1: <t, u>;
+// NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>.
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b,
                                                            const double *__restrict__ V, int64_t ld,
                                                            const double *__restrict__ t_in,
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
-                                                           double *__restrict__ v_out,
                                                            double *__restrict__ u_out,
                                                            double *__restrict__ t_out,
                                                            double *__restrict__ part,
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the arithmetic below
     double vi = 0.0, u = 0.0;
     if (rowvalid && colvalid) {
-      vi = uin / nrm;
+      vi = uin;
       u = tin / nrm;
 #pragma unroll
       for (int k = 0; k < NV; k++) u = u - lane_value(hpack, k) * vk[k];
@@ -171,7 +175,6 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       u = uin;  // zero, or a neighbouring rank's row of the new vector
     }
     if (rr >= rs && rr < re && colowned) {
-      if (v_out) __builtin_nontemporal_store(vi, &v_out[idx]);
       __builtin_nontemporal_store(u, &u_out[idx]);
 #pragma unroll
       for (int k = 0; k < NV; k++) acc[NV + 2 + k] = fma(vk[k], u, acc[NV + 2 + k]);
@@ -202,14 +205,13 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   reduce_store_multi<NQ>(acc, red, part);
 }
 
-// Last step of a cycle: v_i, u_{i+1} and <u_{i+1}, u_{i+1}> only (no operator
+// Last step of a cycle: s_{i+1} and <s_{i+1}, s_{i+1}> only (no operator
 // application follows).  part[workgroup].
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restrict__ V, int64_t ld,
                                                            const double *__restrict__ t_in,
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
-                                                           double *__restrict__ v_out,
                                                            double *__restrict__ u_out, int64_t n,
                                                            double *__restrict__ part,
                                                            const int *__restrict__ stop) {
@@ -226,12 +228,10 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restri
     const double uin = __builtin_nontemporal_load(&u_in[i]);
 #pragma unroll
     for (int k = 0; k < NV; k++) vk[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i]);
-    const double vi = uin / nrm;
     double u = tin / nrm;
 #pragma unroll
     for (int k = 0; k < NV; k++) u = u - h[k] * vk[k];
-    u = u - h[NV] * vi;
-    if (v_out) __builtin_nontemporal_store(vi, &v_out[i]);
+    u = u - h[NV] * uin;
     __builtin_nontemporal_store(u, &u_out[i]);
     a = fma(u, u, a);
   }
@@ -252,27 +252,30 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts_wide(const double *__re
   if (threadIdx.x == 0) tot[q] = r;
 }
 
-// Coefficients of step i from the totals of the sweep that produced u_i and
-// t_i = A u_i (layout of k_arnoldi_fused<i-1>), or, with boot, from the totals
+// Coefficients of step i from the totals of the sweep that produced s_i and
+// t_i = A s_i (layout of k_arnoldi_fused<i-1>), or, with boot, from the totals
 // of the operator kernel applied to the normalised v_i (i + 1 dots, then the i
-// Gram entries of v_i).  Stores column i of G and of H, H[i][i-1] = ||u_i||,
-// coef[0..i] = h and coef[kFusedNormSlot] = ||u_i|| (1 with boot).
+// Gram entries of v_i; sigma_0..sigma_i := 1).  Stores sigma_i = ||s_i||, column i
+// of G and of H, H[i][i-1] = sigma_i, coef[k] = h_k / sigma_k (k <= i) and
+// coef[kFusedNormSlot] = sigma_i.
 __global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ tot, int i, int boot,
                                                       double *__restrict__ G, int gld,
                                                       double *__restrict__ H, int m,
                                                       double *__restrict__ coef,
+                                                      double *__restrict__ sigma,
                                                       const int *__restrict__ stop) {
   if (stopped(stop)) return;
   __shared__ double gs[kFusedMaxM * kFusedMaxM];
   const int lane = threadIdx.x;
   const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
+  const double sk = (boot || lane >= i) ? (lane == i ? nrm : 1.0) : sigma[lane];  // sigma of "my" vector
   // earlier Gram columns
   for (int e = lane; e < i * i; e += 64) {
     const int a = e / i, k = e % i;
     gs[a * kFusedMaxM + k] = a < k ? G[(size_t)a * gld + k] : 0.0;
   }
   if (lane < i) {
-    const double g = boot ? tot[i + 1 + lane] : tot[i + 1 + lane] / nrm;
+    const double g = boot ? tot[i + 1 + lane] : tot[i + 1 + lane] / sk / nrm;
     gs[lane * kFusedMaxM + i] = g;
     G[(size_t)lane * gld + i] = g;
   }
@@ -282,20 +285,40 @@ __global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ 
     if (boot)
       v = tot[lane];
     else
-      v = lane < i ? tot[lane] / nrm : tot[i] / nrm / nrm;
+      v = tot[lane] / sk / nrm;  // lane == i: <t, s_i> / sigma_i^2
   }
   for (int a = 0; a < i; a++) {
     const double ha = __shfl(v, a, 64);
     if (lane > a && lane <= i) v = v - ha * gs[a * kFusedMaxM + lane];
   }
   if (lane <= i) {
-    coef[lane] = v;
+    coef[lane] = v / sk;
     H[(size_t)lane * m + i] = v;
+    if (boot || lane == i) sigma[lane] = sk;
   }
   if (lane == 0) {
     coef[kFusedNormSlot] = nrm;
     if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
   }
+}
+
+// End of a cycle: sigma_m = ||s_m|| from the closing kernel's total, H[m][m-1] = sigma_m.
+__global__ __launch_bounds__(64) void k_fused_finish(const double *__restrict__ tot, int m, double *__restrict__ H,
+                                                      double *__restrict__ sigma, const int *__restrict__ stop) {
+  if (stopped(stop)) return;
+  if (threadIdx.x == 0) {
+    const double nrm = sqrt(tot[0]);
+    sigma[m] = nrm;
+    H[(size_t)m * m + (m - 1)] = nrm;
+  }
+}
+
+// dst = src / sigma[k] (true division, as normalize() in include/matrix.hpp:54-60)
+__global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ src, const double *__restrict__ sigma,
+                                                     int k, double *__restrict__ dst, int64_t n) {
+  const double sg = sigma[k];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    dst[i] = src[i] / sg;
 }
 
 FusedGeom fused_geom(int rows, int P) {
@@ -315,7 +338,7 @@ FusedGeom fused_geom(int rows, int P) {
 
 template <int NV>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
-                    const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
+                    const double *t_in, const double *u_in, const double *coef, double *u_out,
                     double *t_out, double *part, const double *u_halo) {
   constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 4 * kBlock + (2 * NV + 4) * (kBlock / 64));
   static bool configured = false;
@@ -325,41 +348,41 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
     configured = true;
   }
   hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld,
-                     t_in, u_in, coef, v_out, u_out, t_out, part, u_halo, launch_predicate_current());
+                     t_in, u_in, coef, u_out, t_out, part, u_halo, launch_predicate_current());
 }
 
 template <int NV>
 void launch_close_t(hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
-                    const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
-  hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(grid), dim3(kBlock), 0, st, V, ld, t_in, u_in, coef, v_out, u_out,
-                     n, part, launch_predicate_current());
+                    const double *coef, double *u_out, int64_t n, double *part, int grid) {
+  hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(grid), dim3(kBlock), 0, st, V, ld, t_in, u_in, coef, u_out, n, part,
+                     launch_predicate_current());
 }
 
 template <int NV = kFusedMaxM - 1>
 struct FusedTable {
   static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
-                    const double *t_in, const double *u_in, const double *coef, double *v_out, double *u_out,
+                    const double *t_in, const double *u_in, const double *coef, double *u_out,
                     double *t_out, double *part, const double *u_halo) {
     if (nv == NV)
-      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, u_halo);
+      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, u_out, t_out, part, u_halo);
     else
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, u_halo);
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, u_out, t_out, part, u_halo);
   }
   static void close(int nv, hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
-                    const double *coef, double *v_out, double *u_out, int64_t n, double *part, int grid) {
+                    const double *coef, double *u_out, int64_t n, double *part, int grid) {
     if (nv == NV)
-      launch_close_t<NV>(st, V, ld, t_in, u_in, coef, v_out, u_out, n, part, grid);
+      launch_close_t<NV>(st, V, ld, t_in, u_in, coef, u_out, n, part, grid);
     else
-      FusedTable<NV - 1>::close(nv, st, V, ld, t_in, u_in, coef, v_out, u_out, n, part, grid);
+      FusedTable<NV - 1>::close(nv, st, V, ld, t_in, u_in, coef, u_out, n, part, grid);
   }
 };
 
 template <>
 struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const double *, int64_t, const double *,
-                    const double *, const double *, double *, double *, double *, double *, const double *) {}
+                    const double *, const double *, double *, double *, double *, const double *) {}
   static void close(int, hipStream_t, const double *, int64_t, const double *, const double *, const double *,
-                    double *, double *, int64_t, double *, int) {}
+                    double *, int64_t, double *, int) {}
 };
 
 }  // namespace
@@ -370,19 +393,21 @@ int fused_parts(int rows, int cols) {
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *t_in, const double *u_in, const double *coef, double *v_out,
-                          double *u_out, double *t_out, double *part, int *nparts, bool has_halo) {
+                          const double *t_in, const double *coef, double *t_out, double *part, int *nparts,
+                          bool has_halo) {
   const FusedGeom g = fused_geom(rows, cols);
-  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, u_in, coef, v_out, u_out, t_out, part, has_halo ? u_out : nullptr);
+  double *u_out = const_cast<double *>(V) + (int64_t)(nv + 1) * ld;
+  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, V + (int64_t)nv * ld, coef, u_out, t_out, part,
+                      has_halo ? u_out : nullptr);
   *nparts = g.nstrips * g.nbands;
 }
 
-void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in,
-                          const double *u_in, const double *coef, double *v_out, double *u_out, int64_t n,
-                          double *part, int *nparts) {
+void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in, const double *coef,
+                          int64_t n, double *part, int *nparts) {
   int grid = grid_for(n);
   if (grid > 1024) grid = 1024;
-  FusedTable<>::close(nv, st, V, ld, t_in, u_in, coef, v_out, u_out, n, part, grid);
+  FusedTable<>::close(nv, st, V, ld, t_in, V + (int64_t)nv * ld, coef, const_cast<double *>(V) + (int64_t)(nv + 1) * ld,
+                      n, part, grid);
   *nparts = grid;
 }
 
@@ -391,9 +416,17 @@ void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np
 }
 
 void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
-                         int m, double *coef) {
-  hipLaunchKernelGGL(k_fused_coeffs, dim3(1), dim3(64), 0, st, tot, i, boot ? 1 : 0, G, gld, H, m, coef,
+                         int m, double *coef, double *sigma) {
+  hipLaunchKernelGGL(k_fused_coeffs, dim3(1), dim3(64), 0, st, tot, i, boot ? 1 : 0, G, gld, H, m, coef, sigma,
                      launch_predicate_current());
+}
+
+void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma) {
+  hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(64), 0, st, tot, m, H, sigma, launch_predicate_current());
+}
+
+void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n) {
+  hipLaunchKernelGGL(k_unscale, dim3(grid_for(n)), dim3(kBlock), 0, st, src, sigma, k, dst, n);
 }
 
 }  // namespace kry

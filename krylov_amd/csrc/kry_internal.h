@@ -92,8 +92,10 @@ void launch_small_solve(hipStream_t st, const double *H, const double *beta, int
                         double *work);
 // x[k] = sum_i y[i] * V[i*ld + k], accumulated in order i = 0..m-1 from 0.0 (or
 // from x[k] with accumulate); count != nullptr: only the first min(m, *count) terms
+// sigma != nullptr: V[i] holds sigma[i] times the i-th vector, y[i] is divided by sigma[i] first
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m,
-                    double *x, int64_t n, const int *count = nullptr, bool accumulate = false);
+                    double *x, int64_t n, const int *count = nullptr, bool accumulate = false,
+                    const double *sigma = nullptr);
 // x += w
 void launch_add(hipStream_t st, double *x, const double *w, int64_t n);
 // out = a - b; part[b] = sum over block b of out[k]^2 (out may be b)
@@ -120,29 +122,34 @@ void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t
 
 void launch_fill(hipStream_t st, double *x, double v, int64_t n);
 
-// ---- one-sweep Arnoldi step (stencil operator, one rank) ---------------------
+// ---- one-sweep Arnoldi step (5-band grid operator) ----------------------------
+// The vectors these kernels produce stay un-normalised in the basis array V (slot k
+// holds sigma_k v_k); sigma lives in a small device array next to the coefficients.
 // Workgroups (= partial sums per quantity) of a fused sweep over a rows x cols grid.
 int fused_parts(int rows, int cols);
-// Step nv of a cycle: normalise u_in into v_out (basis vector nv; nullptr: u_in is
-// already normalised and stored), orthogonalise t_in / ||u_in|| against the nv + 1
-// vectors with the coefficients coef[0..nv], store the new vector in u_out, A times
-// it in t_out, and the 2 nv + 4 partial sums (see k_arnoldi_fused) in part.
+// Step nv of a cycle: with the coefficients coef[0..nv] (already divided by sigma_k)
+// and coef[kFusedNormSlot] = sigma_nv, store the new vector
+// t_in / sigma_nv - sum_k coef[k] V_k in slot nv + 1, A times it in t_out, and the
+// 2 nv + 4 partial sums (see k_arnoldi_fused) in part.
 // has_halo: the grid rows in front of the first and behind the last row are taken
-// from u_out[-cols..0) and u_out[rows*cols ..) (a neighbouring rank's rows) instead
-// of being treated as zero.
+// from the halo of slot nv + 1 (a neighbouring rank's rows) instead of being treated as zero.
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *t_in, const double *u_in, const double *coef, double *v_out,
-                          double *u_out, double *t_out, double *part, int *nparts, bool has_halo);
-// The same without the operator application and the dots: only <u_out, u_out> in part.
-void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in,
-                          const double *u_in, const double *coef, double *v_out, double *u_out, int64_t n,
-                          double *part, int *nparts);
+                          const double *t_in, const double *coef, double *t_out, double *part, int *nparts,
+                          bool has_halo);
+// The same without the operator application and the dots: only the new vector's
+// squared norm in part (n entries starting at V, t_in: any sub-range of the grid).
+void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in, const double *coef,
+                          int64_t n, double *part, int *nparts);
 // tot[q] = sum_i part[q * np + i], one workgroup per quantity
 void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot);
 // Coefficients of step i from the totals of the previous sweep (boot: of the operator
 // kernel applied to the stored, normalised v_i); see k_fused_coeffs.
 void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
-                         int m, double *coef);
+                         int m, double *coef, double *sigma);
+// sigma[m] = sqrt(tot[0]), H[m][m-1] = sigma[m]
+void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma);
+// dst = src / sigma[k]
+void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n);
 
 // ---- implicit-Euler assembly ------------------------------------------------
 struct IeGeom {

@@ -252,13 +252,15 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
 __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V, int64_t ld,
                                                      const double *__restrict__ y, int m,
                                                      double *__restrict__ x, int64_t n,
-                                                     const int *__restrict__ count, int accumulate) {
+                                                     const int *__restrict__ count, int accumulate,
+                                                     const double *__restrict__ sigma) {
   __shared__ double ys[kMaxM];
   if (count != nullptr) {
     const int c = *count;
     if (c < m) m = c;
   }
-  for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = y[i];
+  // sigma: slot i of V holds sigma[i] times the i-th basis vector
+  for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = sigma != nullptr ? y[i] / sigma[i] : y[i];
   __syncthreads();
   const int64_t n2 = n >> 1;
   d2 *x2 = reinterpret_cast<d2 *>(x);
@@ -1461,9 +1463,9 @@ void launch_small_solve(hipStream_t st, const double *H, const double *beta, int
 }
 
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x,
-                    int64_t n, const int *count, bool accumulate) {
+                    int64_t n, const int *count, bool accumulate, const double *sigma) {
   const int g = grid_for((n + 1) / 2);
-  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n, count, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n, count, accumulate ? 1 : 0, sigma);
 }
 
 void launch_add(hipStream_t st, double *x, const double *w, int64_t n) {
