@@ -212,10 +212,8 @@ struct kry_gmres {
   int last_iters = 0, last_cycles = 0, last_converged = 0;
   double last_relres = 0.0;
   // one-sweep Arnoldi steps (no preconditioner, grid stencil operator): first step that
-  // uses them (< 0: never), the un-normalised new vector (ping-pong), the second
-  // operator-result buffer (the first is w), partial sums, totals, coefficients
+  // uses them (< 0: never; fparts != nullptr: available), partial sums, totals, coefficients
   int fused_from = -1;
-  double *fw = nullptr;
   double *fparts = nullptr, *ftot = nullptr, *fcoef = nullptr;
   // the sweeps leave their vectors un-normalised: slot k of V holds fsigma[k] * v_k
   // (fsigma[k] = 1 for vectors stored by the chain); valid while scaled is set
@@ -750,8 +748,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     int from = 2;
     if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
     if (from > fused_from_max(m)) from = fused_from_max(m);
-    st = dev_alloc(&g->fw, g->ld);
-    if (st == KRY_OK) st = dev_alloc(&g->fsigma, kFusedCoef);
+    st = dev_alloc(&g->fsigma, kFusedCoef);
     if (st == KRY_OK) st = dev_alloc(&g->fparts, (int64_t)kFusedRed * kMaxParts);
     if (st == KRY_OK) st = dev_alloc(&g->ftot, kFusedRed);
     if (st == KRY_OK) st = dev_alloc(&g->fcoef, kFusedCoef);
@@ -768,13 +765,11 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
   (void)hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)g->ld, s);
   if (g->z) (void)hipMemsetAsync(g->z, 0, sizeof(double) * (size_t)g->ld, s);
-  if (g->fw) (void)hipMemsetAsync(g->fw, 0, sizeof(double) * (size_t)g->ld, s);
   if (g->fsigma) launch_fill(s, g->fsigma, 1.0, kFusedCoef);
   // work vectors are addressed at their first owned entry from here on
   g->w += g->halo;
   g->vars += g->halo;
   if (g->z) g->z += g->halo;
-  if (g->fw) g->fw += g->halo;
   g->offset_applied = true;
   launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
   st = launch_ok("kry_gmres_create");
@@ -794,8 +789,7 @@ void kry_gmres_destroy(kry_gmres *g) {
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
                     g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
-                    g->dd, g->ud, g->R, g->G, g->fw ? g->fw - off : nullptr, g->fparts, g->ftot, g->fcoef,
-                    g->fsigma};
+                    g->dd, g->ud, g->R, g->G, g->fparts, g->ftot, g->fcoef, g->fsigma};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
   if (g->ext_h) (void)hipHostFree(g->ext_h);
@@ -824,13 +818,13 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
     g->fused_from = -1;
     return KRY_OK;
   }
-  if (!g->fw)
+  if (!g->fparts)
     return fail(KRY_ERR_STATE, "one-sweep steps need a solver without preconditioner and 3 <= num_iters <= %d", kFusedMaxM);
   g->fused_from = first_step > fused_from_max(g->m) ? fused_from_max(g->m) : first_step;
   return KRY_OK;
 }
 
-int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fw ? g->fused_from : -1; }
+int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fparts ? g->fused_from : -1; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
@@ -1097,13 +1091,13 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   const int64_t P = op->cols;
   const bool ranks = g->ctx->nranks > 1;
   const Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
-  double *tb[2] = {g->w, g->fw};
   int np = 0;
   if (g->halo_row > 0) KCHK(comm_halo(g->ctx, basis(g, i0), g->halo_row, n));
   {
-    // t = A v_from with the dots against v_0..v_from and the Gram column of v_from
+    // the dots of A v_from against v_0..v_from and the Gram column of v_from (the
+    // product itself is recomputed by the first sweep)
     ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
-    op_apply_async(op, basis(g, i0), tb[i0 & 1], i0 + 1, basis(g, 0), g->ld, g->fparts, &np, g->halo_row > 0);
+    op_apply_async(op, basis(g, i0), g->w, i0 + 1, basis(g, 0), g->ld, g->fparts, &np, g->halo_row > 0);
   }
   KCHK(fused_totals(g, 2 * (i0 + 1) - 1, np));
   for (int i = i0; i < m; i++) {
@@ -1117,21 +1111,20 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
       if (ranks) {
         // the new vector on this rank's first and last row, for the neighbours
         ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
-        for (int64_t off : {(int64_t)0, n - P}) {
-          launch_arnoldi_close(st, i, basis(g, 0) + off, g->ld, tb[i & 1] + off, g->fcoef, P, g->fparts, &np);
+        for (int64_t k0 : {(int64_t)0, n - P}) {
+          launch_arnoldi_close(st, i, b, basis(g, 0), g->ld, g->fcoef, n, op->cols, k0, P, true, g->fparts, &np);
           if (n == P) break;
         }
         KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
       }
       {
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
-        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, tb[i & 1], g->fcoef, tb[(i + 1) & 1],
-                             g->fparts, &np, ranks);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks);
       }
       KCHK(fused_totals(g, 2 * i + 4, np));
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-      launch_arnoldi_close(st, i, basis(g, 0), g->ld, tb[i & 1], g->fcoef, n, g->fparts, &np);
+      launch_arnoldi_close(st, i, b, basis(g, 0), g->ld, g->fcoef, n, op->cols, 0, n, ranks, g->fparts, &np);
     }
   }
   KCHK(fused_totals(g, 1, np));
@@ -1268,9 +1261,9 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
   const double *src = basis(g, i);
   if (g->scaled) {
     // the one-sweep steps keep their vectors un-normalised: v_i = slot_i / sigma_i
-    launch_unscale(g->ctx->stream, src, g->fsigma, i, g->fw, g->n);
+    launch_unscale(g->ctx->stream, src, g->fsigma, i, g->w, g->n);
     KCHK(launch_ok("kry_gmres_subspace_vector"));
-    src = g->fw;
+    src = g->w;
   }
   HIPCHK(hipMemcpyAsync(out_host, src, sizeof(double) * g->n, hipMemcpyDeviceToHost, g->ctx->stream));
   HIPCHK(hipStreamSynchronize(g->ctx->stream));
@@ -1338,11 +1331,11 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
     launches[KRY_K_SPMV] += 1;
     for (int i = i0; i < m - 1; i++) {
-      // read: t, the i + 1 stored vectors, operator; written: the new vector and t
-      bytes[KRY_K_FUSED] += (2.0 + i) * N + opb + 2.0 * N;
+      // read: the i + 1 stored vectors, operator; written: the new vector
+      bytes[KRY_K_FUSED] += (1.0 + i) * N + opb + N;
       launches[KRY_K_FUSED] += 1;
     }
-    bytes[KRY_K_MGS_LAST] += (1.0 + m) * N + N;  // closing sweep: t and the m stored vectors read; the new one written
+    bytes[KRY_K_MGS_LAST] += m * N + opb + N;  // closing sweep: the m stored vectors and the operator read; the new vector written
     launches[KRY_K_MGS_LAST] += 1;
   }
   // one normalisation per chain step (none after the one-sweep steps) + ||b|| and v_0 = b/||b||

@@ -5,9 +5,8 @@
 // below reads it once.  The vectors it produces stay UN-NORMALISED in the basis
 // array: slot k holds s_k = sigma_k v_k with sigma_k = ||s_k|| kept in a small
 // array (sigma_k = 1 for the vectors the chain stored).  Per step i the sweep
-// consumes s_0..s_i and t_i = A s_i that the previous sweep left behind, and in
-// ONE pass over the grid
-//     w       = t_i / sigma_i                          (= A v_i up to rounding)
+// consumes s_0..s_i and in ONE pass over the grid
+//     w       = (A s_i) / sigma_i                      (= A v_i up to rounding)
 //     s_{i+1} = w - c_0 s_0 - ... - c_i s_i,  c_k = h_k / sigma_k
 //                                              (modified Gram-Schmidt order)
 //     t_{i+1} = A s_{i+1}
@@ -23,17 +22,19 @@
 // (the final combination x = sum y_k v_k).
 //
 // t = A u needs u at the four neighbours, so the sweep is tiled in two
-// dimensions: a workgroup owns a strip of at most 254 columns (thread = column,
-// one halo column on either side) and walks down a band of rows, keeping the
-// last rows of u in LDS; u is recomputed on the band's two halo rows and the
-// strip's two halo columns (about 1.5 % extra reads).  The basis values of a row
+// dimensions: a workgroup owns a strip of at most 252 columns (thread = column,
+// two halo columns on either side) and walks down a band of rows, keeping the
+// last rows of s_i and of the new vector in LDS; the new vector is recomputed on
+// the band's two halo rows and the strip's inner halo columns (about 1.5 %
+// extra reads).  The basis values of a row
 // are needed once more one row later (for the dots with t), and wait in LDS.
 //
 // On several ranks (row-block decomposition) the rows next to a rank's block
-// belong to its neighbours: the host first evaluates u_{i+1} on the block's
+// belong to its neighbours: the host first evaluates s_{i+1} on the block's
 // first and last row (k_arnoldi_close on those rows), exchanges them, and the
-// sweep reads the neighbours' rows from the halo of u_out instead of
-// recomputing them (u_halo).
+// sweep reads the neighbours' rows from the halo of slot i + 1 instead of
+// recomputing them (u_halo); the neighbours' rows of s_i are in the halo of
+// slot i since the step before.
 //
 // Requirements, checked by the host: 5-band operator whose couplings across
 // the ends of a grid row (band s in column 0, band n in the last column) are
@@ -44,7 +45,7 @@ namespace kry {
 
 namespace {
 
-constexpr int kStripMax = kBlock - 2;  // owned columns per workgroup
+constexpr int kStripMax = kBlock - 4;  // owned columns per workgroup (two halo columns on either side)
 
 struct FusedGeom {
   int rows, P;     // padded grid: rows x P, unknown k = row * P + column
@@ -73,38 +74,45 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
 
 // NV: step number; s_0..s_{NV-1} are read from V, s_NV from u_in (it is slot NV of the
 // same array; a separate argument keeps the register arrays NV long).
-// u: the new vector s_{NV+1}.
+// u: the new vector s_{NV+1}.  t_NV = A s_NV is not stored by the previous sweep but
+// recomputed here from s_NV, whose last rows live in a second LDS ring: that is one
+// vector read and one written less per sweep, at the price of a second halo column on
+// either side of the strip and a second halo row at either end of the band (s_NV only).
+// s_halo: the rows in front of the first / behind the last grid row exist in memory
+// (a neighbouring rank's rows of s_NV, zeros beyond the mesh).
 // part layout (q * gridDim.x + workgroup): q <= NV: <t, s_q>;  NV+1: <t, u>;
-// NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>.
+// NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>   (t = A u).
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b,
                                                            const double *__restrict__ V, int64_t ld,
-                                                           const double *__restrict__ t_in,
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
                                                            double *__restrict__ u_out,
-                                                           double *__restrict__ t_out,
                                                            double *__restrict__ part,
-                                                           const double *__restrict__ u_halo,
+                                                           const double *__restrict__ u_halo, int s_halo,
                                                            const int *__restrict__ stop) {
   if (stopped(stop)) return;
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
-  double *keep = lds;                              // (NV + 1) x kBlock: v_k and v_NV of the previous row
+  double *keep = lds;                               // (NV + 1) x kBlock: s_k of the previous row
   double *ring = keep + (size_t)(NV + 1) * kBlock;  // 4 x kBlock: the last rows of u
-  double *red = ring + 4 * kBlock;                 // NQ x 4
+  double *sring = ring + 4 * kBlock;                // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
+  double *red = sring + 4 * kBlock;                 // NQ x 4
   const int t = threadIdx.x;
   const int strip = blockIdx.x % geo.nstrips, band = blockIdx.x / geo.nstrips;
   const int cs = strip * geo.W;
   const int ce = cs + geo.W < geo.P ? cs + geo.W : geo.P;
-  const int c = cs - 1 + t;
-  const bool colvalid = c >= 0 && c < geo.P && t <= (ce - cs) + 1;
-  const bool colowned = t >= 1 && c < ce;
+  const int wown = ce - cs;
+  const int P = geo.P;
+  const int c = cs - 2 + t;
+  const bool cin = c >= 0 && c < P;
+  const bool scol = cin && t <= wown + 3;            // s_NV is needed here
+  const bool ucol = cin && t >= 1 && t <= wown + 2;  // the new vector is evaluated here
+  const bool colowned = t >= 2 && t <= wown + 1;     // ... and stored / summed here
   const int rs = band * geo.R;
   const int re = rs + geo.R < geo.rows ? rs + geo.R : geo.rows;
-  const int P = geo.P;
 
-  // the coefficients live in the lanes of one register pair (lane k: h_k)
+  // the coefficients live in the lanes of one register pair (lane k: h_k / sigma_k)
   static_assert(NV + 1 <= 64, "one coefficient per lane");
   const double hpack = coef[(t & 63) <= NV ? (t & 63) : 0];
   const double nrm = coef[kFusedNormSlot];
@@ -112,67 +120,82 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
-#pragma unroll
-  for (int k = 0; k <= NV; k++) keep[k * kBlock + t] = 0.0;
 
-  // Loads run one row ahead of the arithmetic: the values of row rr + 1 are requested
-  // before row rr is worked on.
+  auto load_s = [&](int r) -> double {
+    const bool rv = (r >= 0 && r < geo.rows) || (s_halo != 0 && (r == -1 || r == geo.rows));
+    return (rv && scol) ? __builtin_nontemporal_load(&u_in[(int64_t)r * P + c]) : 0.0;
+  };
+  // sring slot of row r: (r - rs + 2) & 3
+  sring[0 * kBlock + t] = load_s(rs - 2);
+  sring[1 * kBlock + t] = load_s(rs - 1);
+  sring[2 * kBlock + t] = load_s(rs);
+
+  // Loads run one row ahead of the arithmetic (s_NV: three rows ahead, it has to pass
+  // through the ring first): the values of round rr + 1 are requested before round rr
+  // is worked on.
   double vn[NV > 0 ? NV : 1];
-  double tin_n = 0.0, uin_n = 0.0;
+  double sn = 0.0, uh_n = 0.0;
   double bn[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   auto fetch = [&](int rr) {
     const bool rowvalid = rr >= 0 && rr < geo.rows;
     const int64_t idx = (int64_t)rr * P + c;
-    tin_n = 0.0;
-    uin_n = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) vn[k] = 0.0;
-    if (rowvalid && colvalid) {
-      tin_n = __builtin_nontemporal_load(&t_in[idx]);
-      uin_n = __builtin_nontemporal_load(&u_in[idx]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) bn[j] = 0.0;
+    uh_n = 0.0;
+    if (rowvalid && ucol) {
 #pragma unroll
       for (int k = 0; k < NV; k++) vn[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idx]);
-    } else if (u_halo != nullptr && !rowvalid && c >= 0 && c < P) {
+      // operator coefficients of row rr: for t_NV(rr) in this round, for t(rr) of the new vector in the next
+      bn[0] = __builtin_nontemporal_load(&b.w[idx]);
+      bn[1] = __builtin_nontemporal_load(&b.s[idx]);
+      bn[2] = __builtin_nontemporal_load(&b.c[idx]);
+      bn[3] = __builtin_nontemporal_load(&b.n[idx]);
+      bn[4] = __builtin_nontemporal_load(&b.e[idx]);
+    } else if (u_halo != nullptr && !rowvalid && cin) {
       // a neighbouring rank's boundary row of the new vector itself (zeros beyond the
       // mesh); u_halo is u_out, read only outside the rows this kernel writes.  The read
       // sits with the other requests of the row: a load inside the arithmetic below would
       // make the compiler drain all outstanding requests there.
-      uin_n = u_halo[idx];
+      uh_n = u_halo[idx];
     }
-    // operator coefficients of row rr - 1, whose application completes one round later
-    if (rr - 1 >= rs && rr - 1 < re && colowned) {
-      const int64_t idq = idx - P;
-      bn[0] = __builtin_nontemporal_load(&b.w[idq]);
-      bn[1] = __builtin_nontemporal_load(&b.s[idq]);
-      bn[2] = __builtin_nontemporal_load(&b.c[idq]);
-      bn[3] = __builtin_nontemporal_load(&b.n[idq]);
-      bn[4] = __builtin_nontemporal_load(&b.e[idq]);
-    }
+    sn = load_s(rr + 2);
   };
   fetch(rs - 1);
+  double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // operator coefficients of the previous row
+  __syncthreads();
 
   for (int rr = rs - 1; rr <= re; rr++) {
     const bool rowvalid = rr >= 0 && rr < geo.rows;
     const int64_t idx = (int64_t)rr * P + c;
-    const int q = rr - 1;  // the row whose operator application completes in this round
+    const int q = rr - 1;  // the row whose operator application (to the new vector) completes in this round
     const bool emit = q >= rs && colowned;
-    const int64_t idq = idx - P;
     double vk[NV > 0 ? NV : 1];
 #pragma unroll
     for (int k = 0; k < NV; k++) vk[k] = vn[k];
-    const double tin = tin_n, uin = uin_n;
-    const double cw = bn[0], cso = bn[1], cc = bn[2], cn = bn[3], cea = bn[4];
+    const double sval = sn, uhv = uh_n;
+    double bc[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) bc[j] = bn[j];
     if (rr < re) fetch(rr + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the arithmetic below
+    const int sl = (rr - rs + 2) & 3;  // sring slot of row rr
     double vi = 0.0, u = 0.0;
-    if (rowvalid && colvalid) {
-      vi = uin;
+    if (rowvalid && ucol) {
+      const double *s0 = sring + sl * kBlock;
+      vi = s0[t];
+      // the first and last column of a grid row have no left / right neighbour in that row
+      const double xs = c > 0 ? s0[t - 1] : 0.0;
+      const double xn = c + 1 < P ? s0[t + 1] : 0.0;
+      const double tin = row_sum(bc[0], bc[1], bc[2], bc[3], bc[4], sring[((sl + 3) & 3) * kBlock + t], xs, vi, xn,
+                                 sring[((sl + 1) & 3) * kBlock + t]);
       u = tin / nrm;
 #pragma unroll
       for (int k = 0; k < NV; k++) u = u - lane_value(hpack, k) * vk[k];
       u = u - lane_value(hpack, NV) * vi;
     } else {
-      u = uin;  // zero, or a neighbouring rank's row of the new vector
+      u = uhv;  // zero, or a neighbouring rank's row of the new vector
     }
     if (rr >= rs && rr < re && colowned) {
       __builtin_nontemporal_store(u, &u_out[idx]);
@@ -183,17 +206,16 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     }
     const int slot = (rr - rs + 1) & 3;
     ring[slot * kBlock + t] = u;
+    sring[((sl + 2) & 3) * kBlock + t] = sval;  // row rr + 2 of s_NV
     __syncthreads();
     if (emit) {
       const double *rq = ring + ((slot + 3) & 3) * kBlock;   // row q
       const double *rm = ring + ((slot + 2) & 3) * kBlock;   // row q - 1
       const double *rp = ring + slot * kBlock;               // row q + 1
-      // the first and last column of a grid row have no left / right neighbour in that row
       const double xs = c > 0 ? rq[t - 1] : 0.0;
       const double xn = c + 1 < P ? rq[t + 1] : 0.0;
       const double uq = rq[t];
-      const double tv = row_sum(cw, cso, cc, cn, cea, rm[t], xs, uq, xn, rp[t]);
-      __builtin_nontemporal_store(tv, &t_out[idq]);
+      const double tv = row_sum(bp[0], bp[1], bp[2], bp[3], bp[4], rm[t], xs, uq, xn, rp[t]);
 #pragma unroll
       for (int k = 0; k <= NV; k++) acc[k] = fma(keep[k * kBlock + t], tv, acc[k]);
       acc[NV + 1] = fma(uq, tv, acc[NV + 1]);
@@ -201,18 +223,22 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 #pragma unroll
     for (int k = 0; k < NV; k++) keep[k * kBlock + t] = vk[k];
     keep[NV * kBlock + t] = vi;
+#pragma unroll
+    for (int j = 0; j < 5; j++) bp[j] = bc[j];
   }
   reduce_store_multi<NQ>(acc, red, part);
 }
 
-// Last step of a cycle: s_{i+1} and <s_{i+1}, s_{i+1}> only (no operator
-// application follows).  part[workgroup].
+// The update alone, on the cnt unknowns from k0 on (the whole vector: last step of a
+// cycle; one grid row: the rows a neighbouring rank needs): s_{NV+1} and its squared
+// norm (part[workgroup]).  n: unknowns of the local vector; s_halo: entries in front of
+// unknown 0 and behind unknown n - 1 exist in memory (one grid row each).
 template <int NV>
-__global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restrict__ V, int64_t ld,
-                                                           const double *__restrict__ t_in,
+__global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double *__restrict__ V, int64_t ld,
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
-                                                           double *__restrict__ u_out, int64_t n,
+                                                           double *__restrict__ u_out, int64_t n, int P,
+                                                           int64_t k0, int64_t cnt, int s_halo,
                                                            double *__restrict__ part,
                                                            const int *__restrict__ stop) {
   if (stopped(stop)) return;
@@ -222,16 +248,22 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(const double *__restri
   for (int k = 0; k <= NV; k++) h[k] = coef[k];
   const double nrm = coef[kFusedNormSlot];
   double a = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < cnt; j += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = k0 + j;
     double vk[NV > 0 ? NV : 1];
-    const double tin = __builtin_nontemporal_load(&t_in[i]);
-    const double uin = __builtin_nontemporal_load(&u_in[i]);
 #pragma unroll
     for (int k = 0; k < NV; k++) vk[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i]);
+    const int col = (int)(i % P);
+    const double xc = u_in[i];
+    const double xw = (s_halo || i >= P) ? u_in[i - P] : 0.0;
+    const double xe = (s_halo || i + P < n) ? u_in[i + P] : 0.0;
+    const double xs = col > 0 ? u_in[i - 1] : 0.0;
+    const double xn = col + 1 < P ? u_in[i + 1] : 0.0;
+    const double tin = row_sum(b.w[i], b.s[i], b.c[i], b.n[i], b.e[i], xw, xs, xc, xn, xe);
     double u = tin / nrm;
 #pragma unroll
     for (int k = 0; k < NV; k++) u = u - h[k] * vk[k];
-    u = u - h[NV] * uin;
+    u = u - h[NV] * xc;
     __builtin_nontemporal_store(u, &u_out[i]);
     a = fma(u, u, a);
   }
@@ -338,51 +370,63 @@ FusedGeom fused_geom(int rows, int P) {
 
 template <int NV>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
-                    const double *t_in, const double *u_in, const double *coef, double *u_out,
-                    double *t_out, double *part, const double *u_halo) {
-  constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 4 * kBlock + (2 * NV + 4) * (kBlock / 64));
+                    const double *u_in, const double *coef, double *u_out, double *part, const double *u_halo,
+                    int s_halo) {
+  constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 8 * kBlock + (2 * NV + 4) * (kBlock / 64));
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld,
-                     t_in, u_in, coef, u_out, t_out, part, u_halo, launch_predicate_current());
+  hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld, u_in,
+                     coef, u_out, part, u_halo, s_halo, launch_predicate_current());
 }
 
+struct CloseArgs {
+  Bands b;
+  const double *V;
+  int64_t ld;
+  const double *coef;
+  int64_t n;
+  int P;
+  int64_t k0, cnt;
+  int s_halo;
+  double *part;
+  int grid;
+};
+
 template <int NV>
-void launch_close_t(hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
-                    const double *coef, double *u_out, int64_t n, double *part, int grid) {
-  hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(grid), dim3(kBlock), 0, st, V, ld, t_in, u_in, coef, u_out, n, part,
-                     launch_predicate_current());
+void launch_close_t(hipStream_t st, const CloseArgs &a) {
+  hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(a.grid), dim3(kBlock), 0, st, a.b, a.V, a.ld, a.V + (int64_t)NV * a.ld,
+                     a.coef, const_cast<double *>(a.V) + (int64_t)(NV + 1) * a.ld, a.n, a.P, a.k0, a.cnt, a.s_halo,
+                     a.part, launch_predicate_current());
 }
 
 template <int NV = kFusedMaxM - 1>
 struct FusedTable {
   static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
-                    const double *t_in, const double *u_in, const double *coef, double *u_out,
-                    double *t_out, double *part, const double *u_halo) {
-    if (nv == NV)
-      launch_fused_t<NV>(st, geo, b, V, ld, t_in, u_in, coef, u_out, t_out, part, u_halo);
-    else
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, t_in, u_in, coef, u_out, t_out, part, u_halo);
+                    const double *coef, double *part, bool u_halo, int s_halo) {
+    if (nv == NV) {
+      double *u_out = const_cast<double *>(V) + (int64_t)(NV + 1) * ld;
+      launch_fused_t<NV>(st, geo, b, V, ld, V + (int64_t)NV * ld, coef, u_out, part, u_halo ? u_out : nullptr, s_halo);
+    } else {
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, coef, part, u_halo, s_halo);
+    }
   }
-  static void close(int nv, hipStream_t st, const double *V, int64_t ld, const double *t_in, const double *u_in,
-                    const double *coef, double *u_out, int64_t n, double *part, int grid) {
+  static void close(int nv, hipStream_t st, const CloseArgs &a) {
     if (nv == NV)
-      launch_close_t<NV>(st, V, ld, t_in, u_in, coef, u_out, n, part, grid);
+      launch_close_t<NV>(st, a);
     else
-      FusedTable<NV - 1>::close(nv, st, V, ld, t_in, u_in, coef, u_out, n, part, grid);
+      FusedTable<NV - 1>::close(nv, st, a);
   }
 };
 
 template <>
 struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const double *, int64_t, const double *,
-                    const double *, const double *, double *, double *, double *, const double *) {}
-  static void close(int, hipStream_t, const double *, int64_t, const double *, const double *, const double *,
-                    double *, int64_t, double *, int) {}
+                    double *, bool, int) {}
+  static void close(int, hipStream_t, const CloseArgs &) {}
 };
 
 }  // namespace
@@ -393,21 +437,18 @@ int fused_parts(int rows, int cols) {
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *t_in, const double *coef, double *t_out, double *part, int *nparts,
-                          bool has_halo) {
+                          const double *coef, double *part, int *nparts, bool has_halo) {
   const FusedGeom g = fused_geom(rows, cols);
-  double *u_out = const_cast<double *>(V) + (int64_t)(nv + 1) * ld;
-  FusedTable<>::sweep(nv, st, g, b, V, ld, t_in, V + (int64_t)nv * ld, coef, u_out, t_out, part,
-                      has_halo ? u_out : nullptr);
+  FusedTable<>::sweep(nv, st, g, b, V, ld, coef, part, has_halo, has_halo ? 1 : 0);
   *nparts = g.nstrips * g.nbands;
 }
 
-void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in, const double *coef,
-                          int64_t n, double *part, int *nparts) {
-  int grid = grid_for(n);
+void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
+                          int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts) {
+  int grid = grid_for(cnt);
   if (grid > 1024) grid = 1024;
-  FusedTable<>::close(nv, st, V, ld, t_in, V + (int64_t)nv * ld, coef, const_cast<double *>(V) + (int64_t)(nv + 1) * ld,
-                      n, part, grid);
+  const CloseArgs a{b, V, ld, coef, n, cols, k0, cnt, has_halo ? 1 : 0, part, grid};
+  FusedTable<>::close(nv, st, a);
   *nparts = grid;
 }
 

@@ -129,17 +129,17 @@ void launch_fill(hipStream_t st, double *x, double v, int64_t n);
 int fused_parts(int rows, int cols);
 // Step nv of a cycle: with the coefficients coef[0..nv] (already divided by sigma_k)
 // and coef[kFusedNormSlot] = sigma_nv, store the new vector
-// t_in / sigma_nv - sum_k coef[k] V_k in slot nv + 1, A times it in t_out, and the
-// 2 nv + 4 partial sums (see k_arnoldi_fused) in part.
-// has_halo: the grid rows in front of the first and behind the last row are taken
-// from the halo of slot nv + 1 (a neighbouring rank's rows) instead of being treated as zero.
+// (A V_nv) / sigma_nv - sum_k coef[k] V_k in slot nv + 1 and the 2 nv + 4 partial sums
+// (see k_arnoldi_fused) in part.
+// has_halo: the grid rows in front of the first and behind the last row exist in the
+// halos of slots nv and nv + 1 (a neighbouring rank's rows, zeros beyond the mesh)
+// instead of being treated as zero.
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *t_in, const double *coef, double *t_out, double *part, int *nparts,
-                          bool has_halo);
-// The same without the operator application and the dots: only the new vector's
-// squared norm in part (n entries starting at V, t_in: any sub-range of the grid).
-void launch_arnoldi_close(hipStream_t st, int nv, const double *V, int64_t ld, const double *t_in, const double *coef,
-                          int64_t n, double *part, int *nparts);
+                          const double *coef, double *part, int *nparts, bool has_halo);
+// The update alone on the cnt unknowns from k0 on (n: unknowns of the local vector):
+// the new vector in slot nv + 1 and its squared norm in part.
+void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
+                          int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts);
 // tot[q] = sum_i part[q * np + i], one workgroup per quantity
 void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot);
 // Coefficients of step i from the totals of the previous sweep (boot: of the operator
