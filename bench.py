@@ -194,8 +194,9 @@ def main():
         "mgs_block_full": "k_mgs_block<%d,%d> (Gram-Schmidt sweep: %d projections applied + %d dots)",
         "mgs_block_part": "k_mgs_block<%d,kc> (Gram-Schmidt sweep: %d projections applied + kc < %d dots)",
         "mgs_last": "k_mgs_block<kp,0> (closing Gram-Schmidt sweep of an Arnoldi step: kp <= %d projections applied + norm)",
-        "arnoldi_fused": "k_arnoldi_fused<i> (one-sweep Arnoldi step: normalise v_i, orthogonalise against v_0..v_i, "
-                         "apply the operator, all dot products of the next step)",
+        "arnoldi_fused": "k_arnoldi_fused<i> (one-sweep Arnoldi step: operator applied to the newest basis vector, "
+                         "orthogonalised against v_0..v_i, operator applied to the result for all dot products of the "
+                         "next step; reads i+1 vectors and the operator, writes one vector)",
     }
     timed = {n: k for n, k in kernels.items() if n in families and k["gbps"]}
     if timed and not ext_stats:

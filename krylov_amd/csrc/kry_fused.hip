@@ -353,16 +353,26 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
     dst[i] = src[i] / sg;
 }
 
-FusedGeom fused_geom(int rows, int P) {
+// Strips and bands for step nv.  About four workgroups per compute unit, bands of at
+// least 32 rows; when the kernel's registers and LDS allow fewer resident workgroups than
+// that (2 per compute unit from 8 earlier vectors on, 1 from 24 on) and the count would
+// leave the last round of workgroups mostly empty, the bands are made taller so that
+// the count fits one round less (2048^2: 567 workgroups = 2.2 rounds of 256 -> 504).
+FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
   g.rows = rows;
   g.P = P;
   g.nstrips = (P + kStripMax - 1) / kStripMax;
   g.W = (P + g.nstrips - 1) / g.nstrips;
-  // about four workgroups per compute unit, bands of at least 32 rows
   int nb = (4 * 256) / g.nstrips;
   if (nb < 1) nb = 1;
   while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
+  const int cap = 256 * (nv <= 7 ? 4 : (nv <= 23 ? 2 : 1));  // workgroups resident at once
+  const int count = g.nstrips * nb, rounds = (count + cap - 1) / cap;
+  if (rounds > 1 && count % cap != 0) {
+    const int nb2 = (cap * (rounds - 1)) / g.nstrips;
+    if (nb2 >= 1 && (double)(g.nstrips * nb2) / (rounds - 1) > (double)count / rounds) nb = nb2;
+  }
   g.R = (rows + nb - 1) / nb;
   g.nbands = (rows + g.R - 1) / g.R;
   return g;
@@ -432,13 +442,13 @@ struct FusedTable<-1> {
 }  // namespace
 
 int fused_parts(int rows, int cols) {
-  const FusedGeom g = fused_geom(rows, cols);
+  const FusedGeom g = fused_geom(rows, cols, 0);  // the largest count over all steps
   return g.nstrips * g.nbands;
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo) {
-  const FusedGeom g = fused_geom(rows, cols);
+  const FusedGeom g = fused_geom(rows, cols, nv);
   FusedTable<>::sweep(nv, st, g, b, V, ld, coef, part, has_halo, has_halo ? 1 : 0);
   *nparts = g.nstrips * g.nbands;
 }

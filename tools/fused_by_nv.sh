@@ -16,6 +16,6 @@ for r in csv.DictReader(open(f)):
         rows.append((int(m.group(1)), float(r["AverageNs"]) / 1e3, int(r["Calls"])))
 N = 8.0 * 8194 * 8194
 for nv, us, calls in sorted(rows):
-    b = (2.0 + nv + 5.0 + 3.0) * N
+    b = (1.0 + nv + 5.0 + 1.0) * N
     print("NV=%2d  %8.1f us  %6.1f GB/s  calls %d" % (nv, us, b / us / 1e3, calls))
 PY

@@ -64,11 +64,8 @@ def main():
     f8 = w8 = None
     if calib:
         f8 = sum(e["fetch_factor"] for e in calib.values()) / len(calib)
-        # the sweep stores two vectors with plain and one with non-temporal 8-byte stores
-        plain = calib.get("strip<16, 1, 256, true, 3, false>", {}).get("write_factor")
-        nt = calib.get("strip<16, 1, 256, true, 3, true>", {}).get("write_factor")
-        if plain and nt:
-            w8 = (2.0 * plain + nt) / 3.0
+        # the sweep stores its one result vector with non-temporal 8-byte stores
+        w8 = calib.get("strip<16, 1, 256, true, 3, true, 0>", {}).get("write_factor")
     for name, c in pmc.items():
         f = fam_of(name)
         if not f or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:

@@ -120,9 +120,9 @@ int main(int argc, char **argv) {
     for (int s = 0; s < nstrips; s++)
       for (int t = 0; t <= Wc + 1; t++) { const int c = s * Wc - 1 + t; if (c >= 0 && c < P) cols++; }
     const double per_stream = 8.0 * (double)rows * (double)cols;
-    printf("CALIB strip<16, 1, 256, true, 0, false> read_bytes %.0f write_bytes 0\n", 16 * per_stream);
-    printf("CALIB strip<16, 1, 256, true, 3, false> read_bytes %.0f write_bytes %.0f\n", 16 * per_stream, 3 * per_stream);
-    printf("CALIB strip<16, 1, 256, true, 3, true> read_bytes %.0f write_bytes %.0f\n", 16 * per_stream, 3 * per_stream);
+    printf("CALIB strip<16, 1, 256, true, 0, false, 0> read_bytes %.0f write_bytes 0\n", 16 * per_stream);
+    printf("CALIB strip<16, 1, 256, true, 3, false, 0> read_bytes %.0f write_bytes %.0f\n", 16 * per_stream, 3 * per_stream);
+    printf("CALIB strip<16, 1, 256, true, 3, true, 0> read_bytes %.0f write_bytes %.0f\n", 16 * per_stream, 3 * per_stream);
     run<16, 1, 256, true>("8 B/lane, reads only", V, ld, rows, P, 1024, out);
     run<16, 1, 256, true, 3>("8 B/lane, 3 write streams", V, ld, rows, P, 1024, out, Wr);
     run<16, 1, 256, true, 3, true>("8 B/lane, 3 NT write streams", V, ld, rows, P, 1024, out, Wr);
