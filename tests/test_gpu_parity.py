@@ -407,6 +407,48 @@ def test_one_sweep_needs_a_grid_stencil(ctx, oracle):
         assert rel(x, x_ref) <= RTOL, first
 
 
+@pytest.mark.parametrize("rows,cols,m", [(3, 250, 8), (4, 253, 8), (5, 254, 8), (3, 505, 8), (4, 757, 6), (40, 7, 12),
+                                         (70, 300, 12), (1, 40, 5), (37, 1, 5)])
+def test_one_sweep_random_grid_stencils(ctx, oracle, rows, cols, m):
+    """Random 5-band grid operators (every band populated up to the edges of the grid,
+    unlike the assembled operator, whose ghost rows and columns are mostly zero) at row
+    lengths around one, two and three 252-column strips, very narrow and very flat grids:
+    the one-sweep steps against the CPU restatement on the equivalent general matrix and
+    against the chain."""
+    rng = np.random.default_rng(1000 * rows + cols)
+    n = rows * cols
+    w, s, nn, e = (rng.uniform(-0.4, 0.4, (rows, cols)) for _ in range(4))
+    c = 3.0 + rng.uniform(0.0, 1.0, (rows, cols))
+    s[:, 0] = 0.0    # no coupling across the ends of a grid row
+    nn[:, -1] = 0.0
+    rowptr, col, val = [0], [], []
+    for k in range(n):
+        entries = {}
+        for name, off, band in (("w", -cols, w), ("s", -1, s), ("c", 0, c), ("n", 1, nn), ("e", cols, e)):
+            if not 0 <= k + off < n or (name == "s" and k % cols == 0) or (name == "n" and k % cols == cols - 1):
+                continue
+            entries[k + off] = entries.get(k + off, 0.0) + band.flat[k]  # cols == 1: w/s and n/e share a column
+        for j in sorted(entries):
+            col.append(j)
+            val.append(entries[j])
+        rowptr.append(len(col))
+    b = rng.uniform(-1.0, 1.0, n)
+    x_ref = oracle.Gmres(n, m, False).solve(oracle.Op.csr(rowptr, col, val), b)
+    op = host.Operator.stencil(ctx, w, s, c, nn, e)
+    g = host.GMRESSolver(ctx, n, m)
+    xs = {}
+    for first in (-1, 0, 2):
+        g.set_one_sweep(first)
+        xs[first] = g.solve(op, b).copy()
+        assert rel(xs[first], x_ref) <= RTOL, first
+        V = np.stack([g.subspace_vector(k) for k in range(m + 1)])
+        # these well-conditioned systems converge within the cycle; Gram-Schmidt loses orthogonality in
+        # proportion to the convergence reached, with the chain as with the sweeps
+        assert np.max(np.abs(V @ V.T - np.eye(m + 1))) <= 1e-6, first
+        assert np.max(np.abs(np.sum(V * V, axis=1) - 1.0)) <= 1e-13, first
+    assert rel(xs[0], xs[-1]) <= 1e-12 and rel(xs[2], xs[-1]) <= 1e-12
+
+
 def test_gmres_general_matrix(ctx, oracle):
     """Stand-alone GMRESSolver<m>.solve(Matrix, Vector) on a dense non-symmetric
     matrix (src/bindpy.cpp:669-707): CSR path."""
