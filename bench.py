@@ -49,6 +49,8 @@ def parse_args():
                     help="solve every step with the restarted, residual-monitored GMRES(m) to this relative "
                          "residual (not the reference's fixed cycle); the value is then iterations actually done per second")
     ap.add_argument("--max-cycles", type=int, default=20)
+    ap.add_argument("--stored-bands", action="store_true",
+                    help="one-sweep steps read the five stored bands instead of evaluating their interior entries")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-m", type=int, default=12, help="Arnoldi steps of the CPU sample cycle")
@@ -145,6 +147,8 @@ def main():
     dev = host.ImplicitEuler(ctx, **getattr(problems, args.problem)(n_side), m=m, bc_time_dependent=False,
                              use_graph=args.graph, tdp=args.tdp, fixed_preconditioning=args.fixed_precond,
                              extended=(args.extended, args.max_cycles) if args.extended > 0.0 else None)
+    if args.stored_bands:
+        dev.set_generated_bands(False)
     ctx.synchronize()
     t_setup = time.perf_counter() - t_setup
     N = dev.n
@@ -196,7 +200,8 @@ def main():
         "mgs_last": "k_mgs_block<kp,0> (closing Gram-Schmidt sweep of an Arnoldi step: kp <= %d projections applied + norm)",
         "arnoldi_fused": "k_arnoldi_fused<i> (one-sweep Arnoldi step: operator applied to the newest basis vector, "
                          "orthogonalised against v_0..v_i, operator applied to the result for all dot products of the "
-                         "next step; reads i+1 vectors and the operator, writes one vector)",
+                         "next step; reads i+1 vectors and the operator -- five bands, or with generated bands the two velocity "
+                         "arrays their interior entries are evaluated from --, writes one vector)",
     }
     timed = {n: k for n, k in kernels.items() if n in families and k["gbps"]}
     if timed and not ext_stats:
@@ -211,7 +216,8 @@ def main():
             try:
                 tj = json.load(open(tfile))
                 if (tj.get("mesh") == n_side and tj.get("m") == m and tj.get("mgs_block") == K
-                        and tj.get("one_sweep_from", -1) == dev.solver().get_one_sweep()):
+                        and tj.get("one_sweep_from", -1) == dev.solver().get_one_sweep()
+                        and bool(tj.get("generated_bands", False)) == dev.generated_bands()):
                     traffic = tj.get("hbm_bytes_per_launch", {}).get(name)
             except Exception:
                 traffic = None
@@ -238,6 +244,7 @@ def main():
                    "mesh": [n_side, n_side], "unknowns": N, "m": m, "dt": dt,
                    "mgs_block": dev.solver().get_mgs_block(),
                    "one_sweep_from": dev.solver().get_one_sweep(),
+                   "generated_bands": dev.generated_bands(),
                    "parallelism": "1 GPU", "graph": bool(args.graph),
                    "solver_mode": ("restarted, residual-monitored, rtol %g" % args.extended) if args.extended > 0.0
                    else "reference: one fixed cycle of m steps"},

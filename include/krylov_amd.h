@@ -264,6 +264,16 @@ int kry_ie_apply_bcs(kry_ie *ie);
 /* ImplicitEuler constructor, second half (include/time_disc.hpp:246-274):
  * ghost fill at t = 0 and the four off-diagonal bands (never refreshed). */
 int kry_ie_init_offdiag(kry_ie *ie);
+/* The off-diagonals of an interior cell are functions of the velocities next to it
+ * at construction time (SecondOrderCentered::Dx_m1 .. Dy_p1, include/space_disc.hpp:
+ * 83-113, frozen by include/time_disc.hpp:246-274) and all interior cells share
+ * one diagonal value (:294-302).  With on != 0 (the default) the one-sweep Arnoldi
+ * steps evaluate those entries from a copy of u and v taken by kry_ie_init_offdiag
+ * (same operations, same bits) instead of reading five stored bands: two streamed
+ * arrays instead of five.  Results are bit-identical either way; ghost rows and
+ * columns always read the stored bands.  get: 1 when the evaluation is in use. */
+int kry_ie_set_generated_bands(kry_ie *ie, int on);
+int kry_ie_get_generated_bands(const kry_ie *ie);
 /* ImplicitEuler::assemble_system, include/time_disc.hpp:291-339 */
 int kry_ie_assemble_system(kry_ie *ie, double dt);
 /* ImplicitEuler::timestep, include/time_disc.hpp:277-289.  *max_delta is the

@@ -81,6 +81,8 @@ SIGNATURES = {
     "kry_ie_set_bc_values": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
     "kry_ie_apply_bcs": (C.c_int, [_vp]),
     "kry_ie_init_offdiag": (C.c_int, [_vp]),
+    "kry_ie_set_generated_bands": (C.c_int, [_vp, C.c_int]),
+    "kry_ie_get_generated_bands": (C.c_int, [_vp]),
     "kry_ie_assemble_system": (C.c_int, [_vp, C.c_double]),
     "kry_ie_timestep": (C.c_int, [_vp, C.c_double, _dp]),
     "kry_ie_timestep_async": (C.c_int, [_vp, C.c_double]),

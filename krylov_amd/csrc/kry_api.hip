@@ -173,6 +173,9 @@ struct kry_op {
   // bands s and n are zero where they would couple the two ends of a grid row
   // (column 0 / the last column): the operator is a true 2-D stencil
   bool wrap_free = false;
+  // interior band entries can be evaluated instead of read (operators assembled by a step object)
+  BandGen gen;
+  bool has_gen = false, use_gen = true;
 };
 
 struct kry_gmres {
@@ -231,6 +234,10 @@ struct kry_ie {
   int64_t halo = 0;  // padding in front of / behind every field
   double *fld[3] = {nullptr, nullptr, nullptr};  // first owned row (halo row in front and behind)
   double *band[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // u and v as they were when the off-diagonals were formed (the reference never refreshes
+  // them, include/time_disc.hpp:246-274), laid out like fld[]: the one-sweep kernels
+  // evaluate the interior band entries from these instead of reading four bands
+  double *snap[2] = {nullptr, nullptr};
   double *rhs = nullptr;
   double *bcvals = nullptr;    // device, 3 * 2 (cx+cy), whole mesh
   double *bcvals_h = nullptr;  // pinned staging
@@ -1119,7 +1126,8 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
       }
       {
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
-        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks,
+                             op->has_gen && op->use_gen ? &op->gen : nullptr);
       }
       KCHK(fused_totals(g, 2 * i + 4, np));
     } else {
@@ -1330,9 +1338,12 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     const int i0 = g->fused_from;
     bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
     launches[KRY_K_SPMV] += 1;
+    // the operator as a sweep reads it: five bands, or the two velocity arrays its interior
+    // entries are evaluated from (the stored bands are then read on ghost rows and columns only)
+    const double opf = op->has_gen && op->use_gen ? 2.0 * N : opb;
     for (int i = i0; i < m - 1; i++) {
       // read: the i + 1 stored vectors, operator; written: the new vector
-      bytes[KRY_K_FUSED] += (1.0 + i) * N + opb + N;
+      bytes[KRY_K_FUSED] += (1.0 + i) * N + opf + N;
       launches[KRY_K_FUSED] += 1;
     }
     bytes[KRY_K_MGS_LAST] += m * N + opb + N;  // closing sweep: the m stored vectors and the operator read; the new vector written
@@ -1486,6 +1497,8 @@ void kry_ie_destroy(kry_ie *ie) {
   for (int f = 0; f < 3; f++)
     if (ie->fld[f]) (void)hipFree(ie->fld[f] - ie->halo);
   for (int b = 0; b < 5; b++) (void)hipFree(ie->band[b]);
+  for (int f = 0; f < 2; f++)
+    if (ie->snap[f]) (void)hipFree(ie->snap[f] - ie->halo);
   (void)hipFree(ie->rhs);
   (void)hipFree(ie->bcvals);
   (void)hipFree(ie->wrap);
@@ -1622,8 +1635,46 @@ int kry_ie_init_offdiag(kry_ie *ie) {
   launch_offdiag(ie->ctx->stream, ie->g, ie->fld[1], ie->fld[2], ie->band[0], ie->band[1], ie->band[2],
                  ie->band[3], ie->band[4]);
   KCHK(launch_ok("init_offdiag"));
+  if (ie->solver && ie->solver->fparts) {
+    // the recipe the one-sweep kernels evaluate the interior band entries from
+    const int P = ie->g.cy + 2;
+    const int64_t fld_len = ie->halo + (ie->nloc + 31) / 32 * 32 + ie->halo;
+    for (int f = 0; f < 2; f++) {
+      if (!ie->snap[f]) {
+        double *base = nullptr;
+        KCHK(dev_alloc(&base, fld_len));
+        ie->snap[f] = base + ie->halo;
+      }
+      HIPCHK(hipMemcpyAsync(ie->snap[f] - ie->halo, ie->fld[1 + f] - ie->halo, sizeof(double) * fld_len,
+                            hipMemcpyDeviceToDevice, ie->ctx->stream));
+    }
+    BandGen &gen = ie->op->gen;
+    gen.u = ie->snap[0];
+    gen.v = ie->snap[1];
+    const int lr = ie->g.row0 >= 1 ? 0 : 1;  // first local row that may be an interior mesh row
+    const bool has_interior = lr < ie->g.rows && ie->g.row0 + lr <= ie->g.cx;
+    gen.cdiag = ie->band[2] + (has_interior ? (int64_t)lr * P + 1 : 0);
+    gen.kx = ie->g.diffusion * ie->g.inv_rp / ie->g.dx;
+    gen.ky = ie->g.diffusion * ie->g.inv_rp / ie->g.dy;
+    gen.dx = ie->g.dx;
+    gen.dy = ie->g.dy;
+    gen.row0 = ie->g.row0;
+    gen.cx = ie->g.cx;
+    gen.cy = ie->g.cy;
+    ie->op->has_gen = true;
+  }
   ie->pending = true;
   return KRY_OK;
+}
+
+int kry_ie_set_generated_bands(kry_ie *ie, int on) {
+  if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  ie->op->use_gen = on != 0;
+  return KRY_OK;
+}
+
+int kry_ie_get_generated_bands(const kry_ie *ie) {
+  return ie && ie->op->has_gen && ie->op->use_gen ? 1 : 0;
 }
 
 int kry_ie_assemble_system(kry_ie *ie, double dt) {

@@ -82,8 +82,11 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
 // (a neighbouring rank's rows of s_NV, zeros beyond the mesh).
 // part layout (q * gridDim.x + workgroup): q <= NV: <t, s_q>;  NV+1: <t, u>;
 // NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>   (t = A u).
-template <int NV>
-__global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b,
+// GEN: the band entries of interior cells are evaluated from the recipe `gen` (velocity
+// snapshots; the operations of k_offdiag, so the same bits) instead of being read: two
+// streamed arrays instead of five.  Ghost rows and columns still read the stored bands.
+template <int NV, bool GEN>
+__global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b, BandGen gen,
                                                            const double *__restrict__ V, int64_t ld,
                                                            const double *__restrict__ u_in,
                                                            const double *__restrict__ coef,
@@ -117,6 +120,22 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   const double hpack = coef[(t & 63) <= NV ? (t & 63) : 0];
   const double nrm = coef[kFusedNormSlot];
 
+  // generated bands: interior columns of this lane, the constants of k_offdiag, the
+  // velocity of the two rows before the one whose coefficients are formed next
+  const bool cint = GEN && c >= 1 && c <= gen.cy;
+  const double gkx = gen.kx, gky = gen.ky;
+  const double gdiag = GEN ? *gen.cdiag : 0.0;
+  auto interior_row = [&](int r) -> bool {
+    const int ip = gen.row0 + r;
+    return ip >= 1 && ip <= gen.cx;
+  };
+  auto load_gu = [&](int r) -> double {  // the fields keep one halo row in front of and behind the grid
+    return (GEN && cint && ucol && r >= -1 && r <= geo.rows) ? __builtin_nontemporal_load(&gen.u[(int64_t)r * P + c])
+                                                             : 0.0;
+  };
+  double gu0 = load_gu(rs - 2), gu1 = load_gu(rs - 1);  // rows rr - 1 and rr of the first round, rr = rs - 1
+  double gun = 0.0;                                     // row rr + 1, requested one round ahead
+
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
@@ -148,11 +167,18 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 #pragma unroll
       for (int k = 0; k < NV; k++) vn[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idx]);
       // operator coefficients of row rr: for t_NV(rr) in this round, for t(rr) of the new vector in the next
-      bn[0] = __builtin_nontemporal_load(&b.w[idx]);
-      bn[1] = __builtin_nontemporal_load(&b.s[idx]);
-      bn[2] = __builtin_nontemporal_load(&b.c[idx]);
-      bn[3] = __builtin_nontemporal_load(&b.n[idx]);
-      bn[4] = __builtin_nontemporal_load(&b.e[idx]);
+      if (GEN && cint && interior_row(rr)) {
+        // the velocities the bottom / top coefficients are made of; neighbouring lanes
+        // read the same lines, so these two requests are served by the vector cache
+        bn[1] = gen.v[idx - 1];
+        bn[3] = gen.v[idx + 1];
+      } else {
+        bn[0] = __builtin_nontemporal_load(&b.w[idx]);
+        bn[1] = __builtin_nontemporal_load(&b.s[idx]);
+        bn[2] = __builtin_nontemporal_load(&b.c[idx]);
+        bn[3] = __builtin_nontemporal_load(&b.n[idx]);
+        bn[4] = __builtin_nontemporal_load(&b.e[idx]);
+      }
     } else if (u_halo != nullptr && !rowvalid && cin) {
       // a neighbouring rank's boundary row of the new vector itself (zeros beyond the
       // mesh); u_halo is u_out, read only outside the rows this kernel writes.  The read
@@ -161,6 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       uh_n = u_halo[idx];
     }
     sn = load_s(rr + 2);
+    if (GEN) gun = load_gu(rr + 1);
   };
   fetch(rs - 1);
   double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // operator coefficients of the previous row
@@ -178,10 +205,23 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     double bc[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) bc[j] = bn[j];
+    const double gum = gu0, gup = gun;  // velocities of rows rr - 1 and rr + 1
+    if (GEN) {
+      gu0 = gu1;
+      gu1 = gun;
+    }
     if (rr < re) fetch(rr + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the arithmetic below
     const int sl = (rr - rs + 2) & 3;  // sring slot of row rr
     double vi = 0.0, u = 0.0;
+    if (GEN && rowvalid && ucol && cint && interior_row(rr)) {
+      // SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1, include/space_disc.hpp:83-113, as k_offdiag forms them
+      bc[0] = (-gum / 2.0 - gkx) / gen.dx;
+      bc[1] = (-bc[1] / 2.0 - gky) / gen.dy;
+      bc[2] = gdiag;
+      bc[3] = (bc[3] / 2.0 - gky) / gen.dy;
+      bc[4] = (gup / 2.0 - gkx) / gen.dx;
+    }
     if (rowvalid && ucol) {
       const double *s0 = sring + sl * kBlock;
       vi = s0[t];
@@ -355,10 +395,10 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
 
 // Strips and bands for step nv.  About four workgroups per compute unit, bands of at
 // least 32 rows; when the kernel's registers and LDS allow fewer resident workgroups than
-// that (2 per compute unit from 8 earlier vectors on, 1 from 24 on) and the count would
+// that (2 per compute unit from about 8 earlier vectors on, 1 from about 24 on) and the count would
 // leave the last round of workgroups mostly empty, the bands are made taller so that
 // the count fits one round less (2048^2: 567 workgroups = 2.2 rounds of 256 -> 504).
-FusedGeom fused_geom(int rows, int P, int nv) {
+FusedGeom fused_geom(int rows, int P, int nv, bool gen = false) {
   FusedGeom g;
   g.rows = rows;
   g.P = P;
@@ -367,7 +407,8 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   int nb = (4 * 256) / g.nstrips;
   if (nb < 1) nb = 1;
   while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
-  const int cap = 256 * (nv <= 7 ? 4 : (nv <= 23 ? 2 : 1));  // workgroups resident at once
+  // workgroups resident at once (128 / 256 registers per lane; evaluating the bands costs 14 registers)
+  const int cap = 256 * (nv <= (gen ? 5 : 7) ? 4 : (nv <= (gen ? 21 : 23) ? 2 : 1));
   const int count = g.nstrips * nb, rounds = (count + cap - 1) / cap;
   if (rounds > 1 && count % cap != 0) {
     const int nb2 = (cap * (rounds - 1)) / g.nstrips;
@@ -378,19 +419,19 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   return g;
 }
 
-template <int NV>
-void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
-                    const double *u_in, const double *coef, double *u_out, double *part, const double *u_halo,
-                    int s_halo) {
+template <int NV, bool GEN>
+void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
+                    int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
+                    const double *u_halo, int s_halo) {
   constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 8 * kBlock + (2 * NV + 4) * (kBlock / 64));
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV, GEN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipLaunchKernelGGL(k_arnoldi_fused<NV>, dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, V, ld, u_in,
-                     coef, u_out, part, u_halo, s_halo, launch_predicate_current());
+  hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN>), dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, gen, V,
+                     ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
 }
 
 struct CloseArgs {
@@ -415,13 +456,17 @@ void launch_close_t(hipStream_t st, const CloseArgs &a) {
 
 template <int NV = kFusedMaxM - 1>
 struct FusedTable {
-  static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const double *V, int64_t ld,
-                    const double *coef, double *part, bool u_halo, int s_halo) {
+  static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen *gen, const double *V,
+                    int64_t ld, const double *coef, double *part, bool u_halo, int s_halo) {
     if (nv == NV) {
       double *u_out = const_cast<double *>(V) + (int64_t)(NV + 1) * ld;
-      launch_fused_t<NV>(st, geo, b, V, ld, V + (int64_t)NV * ld, coef, u_out, part, u_halo ? u_out : nullptr, s_halo);
+      const double *uh = u_halo ? u_out : nullptr;
+      if (gen)
+        launch_fused_t<NV, true>(st, geo, b, *gen, V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo);
+      else
+        launch_fused_t<NV, false>(st, geo, b, BandGen(), V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo);
     } else {
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, V, ld, coef, part, u_halo, s_halo);
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, gen, V, ld, coef, part, u_halo, s_halo);
     }
   }
   static void close(int nv, hipStream_t st, const CloseArgs &a) {
@@ -434,8 +479,8 @@ struct FusedTable {
 
 template <>
 struct FusedTable<-1> {
-  static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const double *, int64_t, const double *,
-                    double *, bool, int) {}
+  static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const BandGen *, const double *, int64_t,
+                    const double *, double *, bool, int) {}
   static void close(int, hipStream_t, const CloseArgs &) {}
 };
 
@@ -447,9 +492,9 @@ int fused_parts(int rows, int cols) {
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *coef, double *part, int *nparts, bool has_halo) {
-  const FusedGeom g = fused_geom(rows, cols, nv);
-  FusedTable<>::sweep(nv, st, g, b, V, ld, coef, part, has_halo, has_halo ? 1 : 0);
+                          const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen) {
+  const FusedGeom g = fused_geom(rows, cols, nv, gen != nullptr);
+  FusedTable<>::sweep(nv, st, g, b, gen, V, ld, coef, part, has_halo, has_halo ? 1 : 0);
   *nparts = g.nstrips * g.nbands;
 }
 

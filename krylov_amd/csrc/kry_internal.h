@@ -25,6 +25,19 @@ struct Bands {
   const double *w, *s, *c, *n, *e;
 };
 
+// Recipe for the interior entries of the bands of an assembled implicit-Euler operator
+// (include/time_disc.hpp:249-274, :294-302): the four off-diagonals of an interior cell
+// are functions of the velocities next to it at the time the off-diagonals were formed,
+// and all interior cells share one diagonal value.  A kernel that holds a recipe
+// evaluates those entries (same operations as k_offdiag, hence the same bits) instead
+// of reading them, and reads the stored bands only on ghost rows and columns.
+struct BandGen {
+  const double *u = nullptr, *v = nullptr;  // velocity snapshots, laid out like the fields (halo row in front and behind)
+  const double *cdiag = nullptr;            // the diagonal entry of one interior cell (any entry when the rank owns none)
+  double kx = 0.0, ky = 0.0, dx = 1.0, dy = 1.0;  // kx = diffusion / (Re Pr) / dx, ky likewise, as k_offdiag forms them
+  int row0 = 0, cx = 0, cy = 0;  // first padded mesh row of the local grid; interior cells of the mesh
+};
+
 // Device-resident state of the restarted solver with residual monitor.
 struct ExtState {
   double tol_abs;  // rtol * ||b||, fixed by the first cycle
@@ -134,8 +147,10 @@ int fused_parts(int rows, int cols);
 // has_halo: the grid rows in front of the first and behind the last row exist in the
 // halos of slots nv and nv + 1 (a neighbouring rank's rows, zeros beyond the mesh)
 // instead of being treated as zero.
+// gen != nullptr: interior band entries are evaluated from the recipe instead of being read.
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *coef, double *part, int *nparts, bool has_halo);
+                          const double *coef, double *part, int *nparts, bool has_halo,
+                          const BandGen *gen = nullptr);
 // The update alone on the cnt unknowns from k0 on (n: unknowns of the local vector):
 // the new vector in slot nv + 1 and its squared norm in part.
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,

@@ -320,6 +320,13 @@ class ImplicitEuler:
     def cur_time(self):
         return capi.lib().kry_ie_time(self.h)
 
+    def set_generated_bands(self, on):
+        """One-sweep steps evaluate the interior band entries from u and v (default) or read the stored bands."""
+        check(capi.lib().kry_ie_set_generated_bands(self.h, int(bool(on))))
+
+    def generated_bands(self):
+        return bool(capi.lib().kry_ie_get_generated_bands(self.h))
+
     def apply_bcs(self):
         self._push_bc_values(self.cur_time())
         check(capi.lib().kry_ie_apply_bcs(self.h))

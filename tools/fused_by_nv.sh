@@ -11,11 +11,14 @@ import csv, glob, re
 f = glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
-    m = re.search(r"k_arnoldi_fused<(\d+)>", r["Name"])
+    m = re.search(r"k_arnoldi_fused<(\d+), *(true|false|\(bool\)[01])>", r["Name"])
     if m:
-        rows.append((int(m.group(1)), float(r["AverageNs"]) / 1e3, int(r["Calls"])))
+        rows.append((int(m.group(1)), float(r["AverageNs"]) / 1e3, int(r["Calls"]), m.group(2) in ("true", "(bool)1")))
 N = 8.0 * 8194 * 8194
-for nv, us, calls in sorted(rows):
-    b = (1.0 + nv + 5.0 + 1.0) * N
-    print("NV=%2d  %8.1f us  %6.1f GB/s  calls %d" % (nv, us, b / us / 1e3, calls))
+for nv, us, calls, gen in sorted(rows):
+    # the nv + 1 stored vectors and the operator read (two velocity arrays when the
+    # interior band entries are evaluated, else five bands), one vector written
+    b = (1.0 + nv + (2.0 if gen else 5.0) + 1.0) * N
+    print("NV=%2d  %s  %8.1f us  %6.1f GB/s  calls %d" % (nv, "generated bands" if gen else "stored bands   ", us,
+                                                        b / us / 1e3, calls))
 PY
