@@ -1661,6 +1661,9 @@ int kry_ie_init_offdiag(kry_ie *ie) {
     gen.row0 = ie->g.row0;
     gen.cx = ie->g.cx;
     gen.cy = ie->g.cy;
+    gen.dg_bottom = 2.0 * ie->bc.weight[KRY_SIDE_BOTTOM] - 1.0;
+    gen.dg_top = 2.0 * ie->bc.weight[KRY_SIDE_TOP] - 1.0;
+    gen.dg_left = 2.0 * ie->bc.weight[KRY_SIDE_LEFT] - 1.0;
     ie->op->has_gen = true;
   }
   ie->pending = true;

@@ -72,6 +72,19 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// The value itself, behind an empty asm statement.  The compiler turns a select on the
+// result of an expensive operation (a division) into a branch around the operation,
+// and the waits for the operation's operands then sit inside that branch: on the path
+// around it the requests count as still in flight, and every later wait is made to
+// allow for them.  A select on a value of unknown origin stays a select.
+__device__ __forceinline__ double opaque(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// The diagonal entry all interior cells share.
+__device__ __forceinline__ double gdiag_of(const BandGen &gen) { return *gen.cdiag; }
+
 // NV: step number; s_0..s_{NV-1} are read from V, s_NV from u_in (it is slot NV of the
 // same array; a separate argument keeps the register arrays NV long).
 // u: the new vector s_{NV+1}.  t_NV = A s_NV is not stored by the previous sweep but
@@ -83,17 +96,28 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
 // part layout (q * gridDim.x + workgroup): q <= NV: <t, s_q>;  NV+1: <t, u>;
 // NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>   (t = A u).
 // GEN: the band entries of interior cells are evaluated from the recipe `gen` (velocity
-// snapshots; the operations of k_offdiag, so the same bits) instead of being read: two
-// streamed arrays instead of five.  Ghost rows and columns still read the stored bands.
+// snapshots; the operations of k_offdiag, so the same bits) and those of ghost rows and
+// columns follow from their position (a 1 towards the interior, the diagonal 2w - 1 of
+// their side): two streamed arrays instead of five, no stored band is read.
+//
+// Memory requests form a rolling window.  Requesting a whole row, working on the
+// previous one and then waiting for everything lets the number of requests in flight
+// drop to zero once per row; with one wavefront per SIMD (more than 256 registers, from
+// 22 earlier vectors on) nothing else covers that gap.  So every request is issued
+// unconditionally -- from an address clamped into the grid, the value of a lane outside
+// it is discarded by a select when it is used -- and in exactly the order in which the
+// next round consumes the values: each value is consumed and the request for its
+// successor issued in the same place, and the wait for any one of them leaves all
+// younger requests in flight.
 template <int NV, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b, BandGen gen,
-                                                           const double *__restrict__ V, int64_t ld,
-                                                           const double *__restrict__ u_in,
-                                                           const double *__restrict__ coef,
-                                                           double *__restrict__ u_out,
-                                                           double *__restrict__ part,
-                                                           const double *__restrict__ u_halo, int s_halo,
-                                                           const int *__restrict__ stop) {
+                                                          const double *__restrict__ V, int64_t ld,
+                                                          const double *__restrict__ u_in,
+                                                          const double *__restrict__ coef,
+                                                          double *__restrict__ u_out,
+                                                          double *__restrict__ part,
+                                                          const double *__restrict__ u_halo, int s_halo,
+                                                          const int *__restrict__ stop) {
   if (stopped(stop)) return;
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
@@ -102,169 +126,183 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   double *sring = ring + 4 * kBlock;                // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
   double *red = sring + 4 * kBlock;                 // NQ x 4
   const int t = threadIdx.x;
+  const int tm = t > 0 ? t - 1 : 0, tp = t + 1 < kBlock ? t + 1 : kBlock - 1;
   const int strip = blockIdx.x % geo.nstrips, band = blockIdx.x / geo.nstrips;
   const int cs = strip * geo.W;
   const int ce = cs + geo.W < geo.P ? cs + geo.W : geo.P;
   const int wown = ce - cs;
-  const int P = geo.P;
+  const int P = geo.P, rows = geo.rows;
   const int c = cs - 2 + t;
   const bool cin = c >= 0 && c < P;
   const bool scol = cin && t <= wown + 3;            // s_NV is needed here
   const bool ucol = cin && t >= 1 && t <= wown + 2;  // the new vector is evaluated here
   const bool colowned = t >= 2 && t <= wown + 1;     // ... and stored / summed here
   const int rs = band * geo.R;
-  const int re = rs + geo.R < geo.rows ? rs + geo.R : geo.rows;
+  const int re = rs + geo.R < rows ? rs + geo.R : rows;
+  // clamped coordinates for the unconditional requests
+  const int cc = c < 0 ? 0 : (c >= P ? P - 1 : c);
+  const int ccm = cc > 0 ? cc - 1 : 0, ccp = cc + 1 < P ? cc + 1 : P - 1;
+  auto rowc = [&](int r) -> int64_t { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); };  // a grid row
+  auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };     // ... or a halo row
+  auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * P + cc]; };
+  auto s_ok = [&](int r) -> bool {
+    return scol && ((r >= 0 && r < rows) || (s_halo != 0 && (r == -1 || r == rows)));
+  };
 
-  // the coefficients live in the lanes of one register pair (lane k: h_k / sigma_k)
   static_assert(NV + 1 <= 64, "one coefficient per lane");
   const double hpack = coef[(t & 63) <= NV ? (t & 63) : 0];
   const double nrm = coef[kFusedNormSlot];
-
-  // generated bands: interior columns of this lane, the constants of k_offdiag, the
-  // velocity of the two rows before the one whose coefficients are formed next
-  const bool cint = GEN && c >= 1 && c <= gen.cy;
-  const double gkx = gen.kx, gky = gen.ky;
-  const double gdiag = GEN ? *gen.cdiag : 0.0;
-  auto interior_row = [&](int r) -> bool {
-    const int ip = gen.row0 + r;
-    return ip >= 1 && ip <= gen.cx;
-  };
-  auto load_gu = [&](int r) -> double {  // the fields keep one halo row in front of and behind the grid
-    return (GEN && cint && ucol && r >= -1 && r <= geo.rows) ? __builtin_nontemporal_load(&gen.u[(int64_t)r * P + c])
-                                                             : 0.0;
-  };
-  double gu0 = load_gu(rs - 2), gu1 = load_gu(rs - 1);  // rows rr - 1 and rr of the first round, rr = rs - 1
-  double gun = 0.0;                                     // row rr + 1, requested one round ahead
 
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
 
-  auto load_s = [&](int r) -> double {
-    const bool rv = (r >= 0 && r < geo.rows) || (s_halo != 0 && (r == -1 || r == geo.rows));
-    return (rv && scol) ? __builtin_nontemporal_load(&u_in[(int64_t)r * P + c]) : 0.0;
-  };
-  // sring slot of row r: (r - rs + 2) & 3
-  sring[0 * kBlock + t] = load_s(rs - 2);
-  sring[1 * kBlock + t] = load_s(rs - 1);
-  sring[2 * kBlock + t] = load_s(rs);
+  {
+    const double d0 = __builtin_nontemporal_load(s_addr(rs - 2));
+    const double d1 = __builtin_nontemporal_load(s_addr(rs - 1));
+    const double d2 = __builtin_nontemporal_load(s_addr(rs));
+    // sring slot of row r: (r - rs + 2) & 3
+    sring[0 * kBlock + t] = s_ok(rs - 2) ? d0 : 0.0;
+    sring[1 * kBlock + t] = s_ok(rs - 1) ? d1 : 0.0;
+    sring[2 * kBlock + t] = s_ok(rs) ? d2 : 0.0;
+  }
 
-  // Loads run one row ahead of the arithmetic (s_NV: three rows ahead, it has to pass
-  // through the ring first): the values of round rr + 1 are requested before round rr
-  // is worked on.
-  double vn[NV > 0 ? NV : 1];
-  double sn = 0.0, uh_n = 0.0;
-  double bn[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  auto fetch = [&](int rr) {
-    const bool rowvalid = rr >= 0 && rr < geo.rows;
-    const int64_t idx = (int64_t)rr * P + c;
-#pragma unroll
-    for (int k = 0; k < NV; k++) vn[k] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) bn[j] = 0.0;
-    uh_n = 0.0;
-    if (rowvalid && ucol) {
-#pragma unroll
-      for (int k = 0; k < NV; k++) vn[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idx]);
-      // operator coefficients of row rr: for t_NV(rr) in this round, for t(rr) of the new vector in the next
-      if (GEN && cint && interior_row(rr)) {
-        // the velocities the bottom / top coefficients are made of; neighbouring lanes
-        // read the same lines, so these two requests are served by the vector cache
-        bn[1] = gen.v[idx - 1];
-        bn[3] = gen.v[idx + 1];
-      } else {
-        bn[0] = __builtin_nontemporal_load(&b.w[idx]);
-        bn[1] = __builtin_nontemporal_load(&b.s[idx]);
-        bn[2] = __builtin_nontemporal_load(&b.c[idx]);
-        bn[3] = __builtin_nontemporal_load(&b.n[idx]);
-        bn[4] = __builtin_nontemporal_load(&b.e[idx]);
-      }
-    } else if (u_halo != nullptr && !rowvalid && cin) {
-      // a neighbouring rank's boundary row of the new vector itself (zeros beyond the
-      // mesh); u_halo is u_out, read only outside the rows this kernel writes.  The read
-      // sits with the other requests of the row: a load inside the arithmetic below would
-      // make the compiler drain all outstanding requests there.
-      uh_n = u_halo[idx];
-    }
-    sn = load_s(rr + 2);
-    if (GEN) gun = load_gu(rr + 1);
+  const double gdiag = GEN ? gdiag_of(gen) : 0.0;
+  // The values requested for a round.  Two sets take turns (the loop below is unrolled
+  // by two): a value requested into the registers the next round reads needs no copy at
+  // the end of the round, which would have to wait for it.
+  struct Req {
+    double v[NV > 0 ? NV : 1];  // s_0 .. s_{NV-1}
+    double b[5];                // five band entries, or (GEN) the two velocities next to the cell in its row
+    double gu;                  // GEN: the velocity one row further
+    double s, uh;               // s_NV two rows further; a neighbouring rank's row of the new vector
   };
-  fetch(rs - 1);
+  Req qa, qb;
+  double gu0 = 0.0, gu1 = 0.0;  // GEN: velocity of rows rr - 1 and rr
+  const bool yin = GEN && c >= 1 && c <= gen.cy;
+  auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {  // what the operator coefficients of row r are made of
+    const int64_t ro = rowc(r) * P;
+    if (GEN) {
+      n.b[1] = gen.v[ro + ccm];
+      n.b[3] = gen.v[ro + ccp];
+      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * P + cc]);
+    } else {
+      n.b[0] = __builtin_nontemporal_load(&b.w[ro + cc]);
+      n.b[1] = __builtin_nontemporal_load(&b.s[ro + cc]);
+      n.b[2] = __builtin_nontemporal_load(&b.c[ro + cc]);
+      n.b[3] = __builtin_nontemporal_load(&b.n[ro + cc]);
+      n.b[4] = __builtin_nontemporal_load(&b.e[ro + cc]);
+    }
+  };
+  auto issue_tail = [&](Req &n, int r) __attribute__((always_inline)) {
+    // a neighbouring rank's boundary row of the new vector itself (u_halo is u_out, read only
+    // outside the rows this kernel writes); without one, a request that costs nothing
+    n.uh = *(u_halo != nullptr ? &u_halo[rowh(r) * P + cc] : coef);
+    n.s = __builtin_nontemporal_load(s_addr(r + 2));
+  };
+  if (GEN) {
+    gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * P + cc]);
+    gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * P + cc]);
+  }
+  issue_op(qa, rs - 1);
+  {
+    const int64_t i0 = rowc(rs - 1) * P + cc;
+#pragma unroll
+    for (int k = 0; k < NV; k++) qa.v[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i0]);
+  }
+  issue_tail(qa, rs - 1);
   double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // operator coefficients of the previous row
+  // The first row's values are awaited here (vmcnt(0)): a request still in flight on entry
+  // to the loop would make every wait inside it allow for that request's position in the
+  // queue as well, which drains the window once per round.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
-  for (int rr = rs - 1; rr <= re; rr++) {
-    const bool rowvalid = rr >= 0 && rr < geo.rows;
+  // one round: consumes the values of set o (row rr), requests those of row rr + 1 into set n
+  auto round = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
+    const bool rowvalid = rr >= 0 && rr < rows;
+    const bool active = rowvalid && ucol;
     const int64_t idx = (int64_t)rr * P + c;
+    const int64_t idxn = rowc(rr + 1) * P + cc;
     const int q = rr - 1;  // the row whose operator application (to the new vector) completes in this round
     const bool emit = q >= rs && colowned;
-    double vk[NV > 0 ? NV : 1];
-#pragma unroll
-    for (int k = 0; k < NV; k++) vk[k] = vn[k];
-    const double sval = sn, uhv = uh_n;
+    // operator coefficients of row rr
     double bc[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) bc[j] = bn[j];
-    const double gum = gu0, gup = gun;  // velocities of rows rr - 1 and rr + 1
     if (GEN) {
+      const double gum = gu0, gup = o.gu;
       gu0 = gu1;
-      gu1 = gun;
-    }
-    if (rr < re) fetch(rr + 1);
-    __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the arithmetic below
-    const int sl = (rr - rs + 2) & 3;  // sring slot of row rr
-    double vi = 0.0, u = 0.0;
-    if (GEN && rowvalid && ucol && cint && interior_row(rr)) {
+      gu1 = gup;
+      issue_op(n, rr + 1);
+      const int ip = gen.row0 + rr;
+      const bool xin = ip >= 1 && ip <= gen.cx;
       // SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1, include/space_disc.hpp:83-113, as k_offdiag forms them
-      bc[0] = (-gum / 2.0 - gkx) / gen.dx;
-      bc[1] = (-bc[1] / 2.0 - gky) / gen.dy;
-      bc[2] = gdiag;
-      bc[3] = (bc[3] / 2.0 - gky) / gen.dy;
-      bc[4] = (gup / 2.0 - gkx) / gen.dx;
-    }
-    if (rowvalid && ucol) {
-      const double *s0 = sring + sl * kBlock;
-      vi = s0[t];
-      // the first and last column of a grid row have no left / right neighbour in that row
-      const double xs = c > 0 ? s0[t - 1] : 0.0;
-      const double xn = c + 1 < P ? s0[t + 1] : 0.0;
-      const double tin = row_sum(bc[0], bc[1], bc[2], bc[3], bc[4], sring[((sl + 3) & 3) * kBlock + t], xs, vi, xn,
-                                 sring[((sl + 1) & 3) * kBlock + t]);
-      u = tin / nrm;
-#pragma unroll
-      for (int k = 0; k < NV; k++) u = u - lane_value(hpack, k) * vk[k];
-      u = u - lane_value(hpack, NV) * vi;
+      const double iw = opaque((-gum / 2.0 - gen.kx) / gen.dx);
+      const double is = opaque((-o.b[1] / 2.0 - gen.ky) / gen.dy);
+      const double in = opaque((o.b[3] / 2.0 - gen.ky) / gen.dy);
+      const double ie = opaque((gup / 2.0 - gen.kx) / gen.dx);
+      const bool inner = xin && yin;
+      // ghost rows as k_assemble leaves them (include/time_disc.hpp:304-337)
+      bc[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
+      bc[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);
+      bc[3] = inner ? in : ((xin && c == 0) ? 1.0 : 0.0);
+      bc[4] = inner ? ie : ((yin && ip == 0) ? 1.0 : 0.0);
+      bc[2] = inner ? gdiag : (xin ? (c == 0 ? gen.dg_bottom : gen.dg_top) : (yin ? gen.dg_left : 1.0));
     } else {
-      u = uhv;  // zero, or a neighbouring rank's row of the new vector
+#pragma unroll
+      for (int j = 0; j < 5; j++) bc[j] = o.b[j];
+      issue_op(n, rr + 1);
     }
+    const int sl = (rr - rs + 2) & 3;  // sring slot of row rr
+    const double *s0 = sring + sl * kBlock;
+    const double vi = s0[t];
+    // the first and last column of a grid row have no left / right neighbour in that row
+    const double xs = c > 0 ? s0[tm] : 0.0;
+    const double xn = c + 1 < P ? s0[tp] : 0.0;
+    const double tin = row_sum(bc[0], bc[1], bc[2], bc[3], bc[4], sring[((sl + 3) & 3) * kBlock + t], xs, vi, xn,
+                               sring[((sl + 1) & 3) * kBlock + t]);
+    double u = tin / nrm;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      n.v[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idxn]);
+      u = u - lane_value(hpack, k) * o.v[k];
+    }
+    u = opaque(u - lane_value(hpack, NV) * vi);
+    issue_tail(n, rr + 1);
+    // outside the columns and rows evaluated here: zero, or a neighbouring rank's row of the new vector
+    u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? o.uh : 0.0);
     if (rr >= rs && rr < re && colowned) {
       __builtin_nontemporal_store(u, &u_out[idx]);
 #pragma unroll
-      for (int k = 0; k < NV; k++) acc[NV + 2 + k] = fma(vk[k], u, acc[NV + 2 + k]);
+      for (int k = 0; k < NV; k++) acc[NV + 2 + k] = fma(o.v[k], u, acc[NV + 2 + k]);
       acc[2 * NV + 2] = fma(vi, u, acc[2 * NV + 2]);
       acc[2 * NV + 3] = fma(u, u, acc[2 * NV + 3]);
     }
     const int slot = (rr - rs + 1) & 3;
     ring[slot * kBlock + t] = u;
-    sring[((sl + 2) & 3) * kBlock + t] = sval;  // row rr + 2 of s_NV
+    sring[((sl + 2) & 3) * kBlock + t] = s_ok(rr + 2) ? o.s : 0.0;  // row rr + 2 of s_NV
     __syncthreads();
     if (emit) {
       const double *rq = ring + ((slot + 3) & 3) * kBlock;   // row q
       const double *rm = ring + ((slot + 2) & 3) * kBlock;   // row q - 1
       const double *rp = ring + slot * kBlock;               // row q + 1
-      const double xs = c > 0 ? rq[t - 1] : 0.0;
-      const double xn = c + 1 < P ? rq[t + 1] : 0.0;
+      const double us = c > 0 ? rq[tm] : 0.0;
+      const double un = c + 1 < P ? rq[tp] : 0.0;
       const double uq = rq[t];
-      const double tv = row_sum(bp[0], bp[1], bp[2], bp[3], bp[4], rm[t], xs, uq, xn, rp[t]);
+      const double tv = row_sum(bp[0], bp[1], bp[2], bp[3], bp[4], rm[t], us, uq, un, rp[t]);
 #pragma unroll
       for (int k = 0; k <= NV; k++) acc[k] = fma(keep[k * kBlock + t], tv, acc[k]);
       acc[NV + 1] = fma(uq, tv, acc[NV + 1]);
     }
 #pragma unroll
-    for (int k = 0; k < NV; k++) keep[k * kBlock + t] = vk[k];
+    for (int k = 0; k < NV; k++) keep[k * kBlock + t] = o.v[k];
     keep[NV * kBlock + t] = vi;
 #pragma unroll
     for (int j = 0; j < 5; j++) bp[j] = bc[j];
+  };
+  for (int rr = rs - 1; rr <= re; rr += 2) {
+    round(rr, qa, qb);
+    if (rr + 1 > re) break;
+    round(rr + 1, qb, qa);
   }
   reduce_store_multi<NQ>(acc, red, part);
 }
@@ -395,10 +433,10 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
 
 // Strips and bands for step nv.  About four workgroups per compute unit, bands of at
 // least 32 rows; when the kernel's registers and LDS allow fewer resident workgroups than
-// that (2 per compute unit from about 8 earlier vectors on, 1 from about 24 on) and the count would
+// that (3 per compute unit from 6 earlier vectors on, 2 from 11 on, 1 from 22 on) and the count would
 // leave the last round of workgroups mostly empty, the bands are made taller so that
 // the count fits one round less (2048^2: 567 workgroups = 2.2 rounds of 256 -> 504).
-FusedGeom fused_geom(int rows, int P, int nv, bool gen = false) {
+FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
   g.rows = rows;
   g.P = P;
@@ -407,8 +445,8 @@ FusedGeom fused_geom(int rows, int P, int nv, bool gen = false) {
   int nb = (4 * 256) / g.nstrips;
   if (nb < 1) nb = 1;
   while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
-  // workgroups resident at once (128 / 256 registers per lane; evaluating the bands costs 14 registers)
-  const int cap = 256 * (nv <= (gen ? 5 : 7) ? 4 : (nv <= (gen ? 21 : 23) ? 2 : 1));
+  // workgroups resident at once: 4 per compute unit up to 128 registers per lane, 3 up to 168, 2 up to 256
+  const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv <= 21 ? 2 : 1)));
   const int count = g.nstrips * nb, rounds = (count + cap - 1) / cap;
   if (rounds > 1 && count % cap != 0) {
     const int nb2 = (cap * (rounds - 1)) / g.nstrips;
@@ -493,7 +531,7 @@ int fused_parts(int rows, int cols) {
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen) {
-  const FusedGeom g = fused_geom(rows, cols, nv, gen != nullptr);
+  const FusedGeom g = fused_geom(rows, cols, nv);
   FusedTable<>::sweep(nv, st, g, b, gen, V, ld, coef, part, has_halo, has_halo ? 1 : 0);
   *nparts = g.nstrips * g.nbands;
 }

@@ -36,6 +36,10 @@ struct BandGen {
   const double *cdiag = nullptr;            // the diagonal entry of one interior cell (any entry when the rank owns none)
   double kx = 0.0, ky = 0.0, dx = 1.0, dy = 1.0;  // kx = diffusion / (Re Pr) / dx, ky likewise, as k_offdiag forms them
   int row0 = 0, cx = 0, cy = 0;  // first padded mesh row of the local grid; interior cells of the mesh
+  // diagonal entries 2w - 1 of the ghost rows (include/time_disc.hpp:304-337): bottom, top, and
+  // left, which the right ghost column shares (:335-336); their only other entry is a 1 towards
+  // the interior, and the corner entries (no unknowns) carry a unit diagonal
+  double dg_bottom = 0.0, dg_top = 0.0, dg_left = 0.0;
 };
 
 // Device-resident state of the restarted solver with residual monitor.
