@@ -270,13 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     issue_tail(n, rr + 1);
     // outside the columns and rows evaluated here: zero, or a neighbouring rank's row of the new vector
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? o.uh : 0.0);
-    if (rr >= rs && rr < re && colowned) {
-      __builtin_nontemporal_store(u, &u_out[idx]);
-#pragma unroll
-      for (int k = 0; k < NV; k++) acc[NV + 2 + k] = fma(o.v[k], u, acc[NV + 2 + k]);
-      acc[2 * NV + 2] = fma(vi, u, acc[2 * NV + 2]);
-      acc[2 * NV + 3] = fma(u, u, acc[2 * NV + 3]);
-    }
+    if (rr >= rs && rr < re && colowned) __builtin_nontemporal_store(u, &u_out[idx]);
     const int slot = (rr - rs + 1) & 3;
     ring[slot * kBlock + t] = u;
     sring[((sl + 2) & 3) * kBlock + t] = s_ok(rr + 2) ? o.s : 0.0;  // row rr + 2 of s_NV
@@ -289,9 +283,16 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       const double un = c + 1 < P ? rq[tp] : 0.0;
       const double uq = rq[t];
       const double tv = row_sum(bp[0], bp[1], bp[2], bp[3], bp[4], rm[t], us, uq, un, rp[t]);
+      // both sets of dot products of row q from the parked values: the registers that
+      // received s_k are then free as soon as the update has used them
 #pragma unroll
-      for (int k = 0; k <= NV; k++) acc[k] = fma(keep[k * kBlock + t], tv, acc[k]);
+      for (int k = 0; k <= NV; k++) {
+        const double sk = keep[k * kBlock + t];
+        acc[k] = fma(sk, tv, acc[k]);
+        acc[NV + 2 + k] = fma(sk, uq, acc[NV + 2 + k]);
+      }
       acc[NV + 1] = fma(uq, tv, acc[NV + 1]);
+      acc[2 * NV + 3] = fma(uq, uq, acc[2 * NV + 3]);
     }
 #pragma unroll
     for (int k = 0; k < NV; k++) keep[k * kBlock + t] = o.v[k];

@@ -87,6 +87,7 @@ def main():
             calls[f] = calls.get(f, 0) + int(r["Calls"])
     out = {
         "mesh": mesh, "m": m, "mgs_block": block, "one_sweep_from": cfg.get("one_sweep_from"),
+        "generated_bands": bool(cfg.get("generated_bands", False)),
         "calibration_8_byte_lanes": {"per_kernel": calib, "fetch_factor": f8, "write_factor": w8},
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over one benchmark step "
                   "(tools/collect_evidence.sh); per kernel family the dispatch-weighted mean of "
