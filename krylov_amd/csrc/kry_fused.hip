@@ -46,6 +46,8 @@ namespace kry {
 namespace {
 
 constexpr int kStripMax = kBlock - 4;  // owned columns per workgroup (two halo columns on either side)
+constexpr int kStoreRows = 8;          // rows of the new vector stored together
+constexpr int kRing = 8;               // rows of the new vector kept in LDS (power of two, >= kStoreRows and >= 4)
 
 struct FusedGeom {
   int rows, P;     // padded grid: rows x P, unknown k = row * P + column
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
   double *keep = lds;                               // (NV + 1) x kBlock: s_k of the previous row
-  double *ring = keep + (size_t)(NV + 1) * kBlock;  // 4 x kBlock: the last rows of u
-  double *sring = ring + 4 * kBlock;                // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
+  double *ring = keep + (size_t)(NV + 1) * kBlock;  // kRing x kBlock: the last rows of u
+  double *sring = ring + kRing * kBlock;            // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
   double *red = sring + 4 * kBlock;                 // NQ x 4
   const int t = threadIdx.x;
   const int tm = t > 0 ? t - 1 : 0, tp = t + 1 < kBlock ? t + 1 : kBlock - 1;
@@ -222,7 +224,6 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   auto round = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
     const bool rowvalid = rr >= 0 && rr < rows;
     const bool active = rowvalid && ucol;
-    const int64_t idx = (int64_t)rr * P + c;
     const int64_t idxn = rowc(rr + 1) * P + cc;
     const int q = rr - 1;  // the row whose operator application (to the new vector) completes in this round
     const bool emit = q >= rs && colowned;
@@ -270,15 +271,26 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     issue_tail(n, rr + 1);
     // outside the columns and rows evaluated here: zero, or a neighbouring rank's row of the new vector
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? o.uh : 0.0);
-    if (rr >= rs && rr < re && colowned) __builtin_nontemporal_store(u, &u_out[idx]);
-    const int slot = (rr - rs + 1) & 3;
+    const int slot = (rr - rs + 1) & (kRing - 1);
     ring[slot * kBlock + t] = u;
+    // The new vector is stored kStoreRows rows at a time, from the ring (a thread reads back
+    // what it wrote itself): the memory side handles a few long bursts of writes among
+    // the reads better than a steady trickle.
+    const int done = rr - rs + 1;  // owned rows evaluated so far
+    if (rr >= rs && rr < re && ((done & (kStoreRows - 1)) == 0 || rr == re - 1) && colowned) {
+      const int first = rr - ((done - 1) & (kStoreRows - 1));
+#pragma unroll
+      for (int j = 0; j < kStoreRows; j++) {
+        const int r = first + j;
+        if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+      }
+    }
     sring[((sl + 2) & 3) * kBlock + t] = s_ok(rr + 2) ? o.s : 0.0;  // row rr + 2 of s_NV
     __syncthreads();
     if (emit) {
-      const double *rq = ring + ((slot + 3) & 3) * kBlock;   // row q
-      const double *rm = ring + ((slot + 2) & 3) * kBlock;   // row q - 1
-      const double *rp = ring + slot * kBlock;               // row q + 1
+      const double *rq = ring + ((slot + kRing - 1) & (kRing - 1)) * kBlock;  // row q
+      const double *rm = ring + ((slot + kRing - 2) & (kRing - 1)) * kBlock;  // row q - 1
+      const double *rp = ring + slot * kBlock;                                // row q + 1
       const double us = c > 0 ? rq[tm] : 0.0;
       const double un = c + 1 < P ? rq[tp] : 0.0;
       const double uq = rq[t];
@@ -462,7 +474,8 @@ template <int NV, bool GEN>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
                     int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
                     const double *u_halo, int s_halo) {
-  constexpr size_t lds = sizeof(double) * ((size_t)(NV + 1) * kBlock + 8 * kBlock + (2 * NV + 4) * (kBlock / 64));
+  constexpr size_t lds =
+      sizeof(double) * ((size_t)(NV + 1) * kBlock + (kRing + 4) * kBlock + (2 * NV + 4) * (kBlock / 64));
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV, GEN>),
