@@ -46,8 +46,12 @@ namespace kry {
 namespace {
 
 constexpr int kStripMax = kBlock - 4;  // owned columns per workgroup (two halo columns on either side)
-constexpr int kStoreRows = 8;          // rows of the new vector stored together
-constexpr int kRing = 8;               // rows of the new vector kept in LDS (power of two, >= kStoreRows and >= 4)
+// Rows of the new vector stored together = rows of it kept in LDS (a power of two, at least 4).
+// Longer bursts are better as long as the LDS they take does not cost a resident workgroup
+// (4 workgroups per compute unit are resident up to 5 earlier vectors, 3 up to 10, 2 up to 21
+// by registers; a workgroup needs (nv + 1 + rows + 4) x 2 KB + the reduction scratch of the
+// 160 KB); the steps were measured per instantiation on an 8192 x 8192 grid.
+constexpr int store_rows(int nv) { return nv <= 7 ? 8 : (nv <= 18 ? 16 : (nv <= 21 ? 8 : (nv <= 29 ? 32 : 16))); }
 
 struct FusedGeom {
   int rows, P;     // padded grid: rows x P, unknown k = row * P + column
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   constexpr int NQ = 2 * NV + 4;
   extern __shared__ double lds[];
   double *keep = lds;                               // (NV + 1) x kBlock: s_k of the previous row
+  constexpr int kStoreRows = store_rows(NV), kRing = kStoreRows;
   double *ring = keep + (size_t)(NV + 1) * kBlock;  // kRing x kBlock: the last rows of u
   double *sring = ring + kRing * kBlock;            // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
   double *red = sring + 4 * kBlock;                 // NQ x 4
@@ -475,7 +480,8 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
                     int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
                     const double *u_halo, int s_halo) {
   constexpr size_t lds =
-      sizeof(double) * ((size_t)(NV + 1) * kBlock + (kRing + 4) * kBlock + (2 * NV + 4) * (kBlock / 64));
+      sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 4) * (kBlock / 64));
+  static_assert(lds <= 160 * 1024, "LDS of one compute unit");
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV, GEN>),
