@@ -39,6 +39,8 @@
 // Requirements, checked by the host: 5-band operator whose couplings across
 // the ends of a grid row (band s in column 0, band n in the last column) are
 // zero, m <= kFusedMaxM.
+#include <stdlib.h>
+
 #include "kry_device.h"
 
 namespace kry {
@@ -325,6 +327,302 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   reduce_store_multi<NQ>(acc, red, part);
 }
 
+// The same sweep by a workgroup of 512 threads whose two halves share the columns of the
+// strip and split the basis vectors: half 0 evaluates the operator coefficients, w and the
+// first NA updates, half 1 the remaining updates (in the same order, continuing from half
+// 0's value, so every bit of the new vector is the same), stores the result and applies the
+// operator to it; each half requests, parks and accumulates the dot products of its own
+// vectors.  Per lane that is half the registers, so two wavefronts fit a SIMD where the
+// kernel above runs with one, and the arithmetic of one overlaps the waiting of the other.
+constexpr int kSplitBlock = 2 * kBlock;
+constexpr int split_store_rows(int nv) { return nv <= 40 ? 16 : 8; }
+
+template <int NV, bool GEN>
+__global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Bands b, BandGen gen,
+                                                                const double *__restrict__ V, int64_t ld,
+                                                                const double *__restrict__ u_in,
+                                                                const double *__restrict__ coef,
+                                                                double *__restrict__ u_out,
+                                                                double *__restrict__ part,
+                                                                const double *__restrict__ u_halo, int s_halo,
+                                                                const int *__restrict__ stop) {
+  if (stopped(stop)) return;
+  constexpr int NQ = 2 * NV + 4;
+  constexpr int NA = (NV + 1) / 2, NB = NV - NA;  // vectors of half 0: [0, NA), of half 1: [NA, NV) and s_NV
+  static_assert(NB >= 1, "both halves need a vector");
+  constexpr int kStoreRows = split_store_rows(NV), kRing = kStoreRows;
+  extern __shared__ double lds[];
+  double *keep = lds;                               // (NV + 1) x kBlock: s_k of the previous row
+  double *ring = keep + (size_t)(NV + 1) * kBlock;  // kRing x kBlock: the last rows of u
+  double *sring = ring + kRing * kBlock;            // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
+  double *xa = sring + 4 * kBlock;                  // kBlock: half 0's value of the update chain
+  double *bcs = xa + kBlock;                        // 5 x kBlock: operator coefficients of row rr
+  double *tvs = bcs + 5 * kBlock;                   // kBlock: the operator applied to the new vector, row rr - 1
+  double *red = tvs + kBlock;                       // NQ x 4
+  const int half = threadIdx.x >> 8, t = threadIdx.x & (kBlock - 1);
+  const int lane = t & 63, wv = t >> 6;
+  const int tm = t > 0 ? t - 1 : 0, tp = t + 1 < kBlock ? t + 1 : kBlock - 1;
+  const int strip = blockIdx.x % geo.nstrips, band = blockIdx.x / geo.nstrips;
+  const int cs = strip * geo.W;
+  const int ce = cs + geo.W < geo.P ? cs + geo.W : geo.P;
+  const int wown = ce - cs;
+  const int P = geo.P, rows = geo.rows;
+  const int c = cs - 2 + t;
+  const bool cin = c >= 0 && c < P;
+  const bool scol = cin && t <= wown + 3;
+  const bool ucol = cin && t >= 1 && t <= wown + 2;
+  const bool colowned = t >= 2 && t <= wown + 1;
+  const int rs = band * geo.R;
+  const int re = rs + geo.R < rows ? rs + geo.R : rows;
+  const int cc = c < 0 ? 0 : (c >= P ? P - 1 : c);
+  const int ccm = cc > 0 ? cc - 1 : 0, ccp = cc + 1 < P ? cc + 1 : P - 1;
+  auto rowc = [&](int r) -> int64_t { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); };
+  auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };
+  auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * P + cc]; };
+  auto s_ok = [&](int r) -> bool {
+    return scol && ((r >= 0 && r < rows) || (s_halo != 0 && (r == -1 || r == rows)));
+  };
+  const int kb = half ? NA : 0;  // first vector of this half
+  // lane k: the coefficient of this half's k-th vector (half 1: and that of s_NV in lane NB)
+  const double hpack = coef[kb + lane <= NV ? kb + lane : 0];
+  const double nrm = coef[kFusedNormSlot];
+  const double *Vh = V + (int64_t)kb * ld;
+
+  if (half == 0) {
+    const double d0 = __builtin_nontemporal_load(s_addr(rs - 2));
+    const double d1 = __builtin_nontemporal_load(s_addr(rs - 1));
+    const double d2 = __builtin_nontemporal_load(s_addr(rs));
+    sring[0 * kBlock + t] = s_ok(rs - 2) ? d0 : 0.0;
+    sring[1 * kBlock + t] = s_ok(rs - 1) ? d1 : 0.0;
+    sring[2 * kBlock + t] = s_ok(rs) ? d2 : 0.0;
+  }
+  // accumulators of this half: <t, s_k> and <s_k, u> of its vectors (index NB of half 1: s_NV),
+  // half 0 also <t, u> and <u, u>
+  double aT[NA + 1], aS[NA + 1], aTU = 0.0, aUU = 0.0;
+#pragma unroll
+  for (int k = 0; k <= NA; k++) aT[k] = aS[k] = 0.0;
+
+  struct Req {
+    double v[NA];
+    double b[5];
+    double gu;
+    double s, uh;
+  };
+  Req qa, qb;
+  const double gdiag = GEN ? gdiag_of(gen) : 0.0;
+  double gu0 = 0.0, gu1 = 0.0;
+  const bool yin = GEN && c >= 1 && c <= gen.cy;
+  auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {
+    const int64_t ro = rowc(r) * P;
+    if (GEN) {
+      n.b[1] = gen.v[ro + ccm];
+      n.b[3] = gen.v[ro + ccp];
+      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * P + cc]);
+    } else {
+      n.b[0] = __builtin_nontemporal_load(&b.w[ro + cc]);
+      n.b[1] = __builtin_nontemporal_load(&b.s[ro + cc]);
+      n.b[2] = __builtin_nontemporal_load(&b.c[ro + cc]);
+      n.b[3] = __builtin_nontemporal_load(&b.n[ro + cc]);
+      n.b[4] = __builtin_nontemporal_load(&b.e[ro + cc]);
+    }
+  };
+  // this half's vectors of one row
+  auto issue_row = [&](Req &n, int64_t idx) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) n.v[k] = __builtin_nontemporal_load(&Vh[(int64_t)k * ld + idx]);
+    if (NA > NB && half == 0) n.v[NA - 1] = __builtin_nontemporal_load(&Vh[(int64_t)(NA - 1) * ld + idx]);
+  };
+  {
+    const int64_t i0 = rowc(rs - 1) * P + cc;
+    if (half == 0) {
+      if (GEN) {
+        gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * P + cc]);
+        gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * P + cc]);
+      }
+      issue_op(qa, rs - 1);
+      issue_row(qa, i0);
+      qa.s = __builtin_nontemporal_load(s_addr(rs + 1));
+    } else {
+      issue_row(qa, i0);
+      qa.uh = *(u_halo != nullptr ? &u_halo[rowh(rs - 1) * P + cc] : coef);
+    }
+  }
+  double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // half 1: operator coefficients of the previous row
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  // dot products of row q = rr - 1 from the parked values, then this row's values are parked
+  auto emit_park = [&](const int rr, Req &o, const double vi) __attribute__((always_inline)) {
+    const int q = rr - 1;
+    const int slot = (rr - rs + 1) & (kRing - 1);
+    if (q >= rs && colowned) {
+      const double tv = tvs[t];
+      const double uq = ring[((slot + kRing - 1) & (kRing - 1)) * kBlock + t];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const double sk = keep[(kb + k) * kBlock + t];
+        aT[k] = fma(sk, tv, aT[k]);
+        aS[k] = fma(sk, uq, aS[k]);
+      }
+      if (half == 0) {
+        if (NA > NB) {
+          const double sk = keep[(NA - 1) * kBlock + t];
+          aT[NA - 1] = fma(sk, tv, aT[NA - 1]);
+          aS[NA - 1] = fma(sk, uq, aS[NA - 1]);
+        }
+        aTU = fma(uq, tv, aTU);
+        aUU = fma(uq, uq, aUU);
+      } else {
+        const double sk = keep[NV * kBlock + t];
+        aT[NB] = fma(sk, tv, aT[NB]);
+        aS[NB] = fma(sk, uq, aS[NB]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) keep[(kb + k) * kBlock + t] = o.v[k];
+    if (half == 0) {
+      if (NA > NB) keep[(NA - 1) * kBlock + t] = o.v[NA - 1];
+    } else {
+      keep[NV * kBlock + t] = vi;
+    }
+  };
+
+  auto round0 = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
+    const int64_t idxn = rowc(rr + 1) * P + cc;
+    double bc[5];
+    if (GEN) {
+      const double gum = gu0, gup = o.gu;
+      gu0 = gu1;
+      gu1 = gup;
+      issue_op(n, rr + 1);
+      const int ip = gen.row0 + rr;
+      const bool xin = ip >= 1 && ip <= gen.cx;
+      const double iw = opaque((-gum / 2.0 - gen.kx) / gen.dx);
+      const double is = opaque((-o.b[1] / 2.0 - gen.ky) / gen.dy);
+      const double in = opaque((o.b[3] / 2.0 - gen.ky) / gen.dy);
+      const double ie = opaque((gup / 2.0 - gen.kx) / gen.dx);
+      const bool inner = xin && yin;
+      bc[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
+      bc[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);
+      bc[3] = inner ? in : ((xin && c == 0) ? 1.0 : 0.0);
+      bc[4] = inner ? ie : ((yin && ip == 0) ? 1.0 : 0.0);
+      bc[2] = inner ? gdiag : (xin ? (c == 0 ? gen.dg_bottom : gen.dg_top) : (yin ? gen.dg_left : 1.0));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 5; j++) bc[j] = o.b[j];
+      issue_op(n, rr + 1);
+    }
+    const int sl = (rr - rs + 2) & 3;
+    const double *s0 = sring + sl * kBlock;
+    const double vi = s0[t];
+    const double xs = c > 0 ? s0[tm] : 0.0;
+    const double xn = c + 1 < P ? s0[tp] : 0.0;
+    const double tin = row_sum(bc[0], bc[1], bc[2], bc[3], bc[4], sring[((sl + 3) & 3) * kBlock + t], xs, vi, xn,
+                               sring[((sl + 1) & 3) * kBlock + t]);
+    double u = tin / nrm;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+      n.v[k] = __builtin_nontemporal_load(&Vh[(int64_t)k * ld + idxn]);
+      u = u - lane_value(hpack, k) * o.v[k];
+    }
+    xa[t] = opaque(u);
+#pragma unroll
+    for (int j = 0; j < 5; j++) bcs[j * kBlock + t] = bc[j];
+    const double sval = o.s;
+    n.s = __builtin_nontemporal_load(s_addr(rr + 3));
+    sring[((sl + 2) & 3) * kBlock + t] = s_ok(rr + 2) ? sval : 0.0;  // row rr + 2 of s_NV
+    __syncthreads();
+    __syncthreads();
+    emit_park(rr, o, 0.0);
+  };
+
+  auto round1 = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
+    const bool rowvalid = rr >= 0 && rr < rows;
+    const bool active = rowvalid && ucol;
+    const int64_t idxn = rowc(rr + 1) * P + cc;
+    __syncthreads();
+    double u = xa[t];
+    const int sl = (rr - rs + 2) & 3;
+    const double vi = sring[sl * kBlock + t];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      n.v[k] = __builtin_nontemporal_load(&Vh[(int64_t)k * ld + idxn]);
+      u = u - lane_value(hpack, k) * o.v[k];
+    }
+    u = opaque(u - lane_value(hpack, NB) * vi);
+    const double uhv = o.uh;
+    n.uh = *(u_halo != nullptr ? &u_halo[rowh(rr + 1) * P + cc] : coef);
+    u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? uhv : 0.0);
+    const int slot = (rr - rs + 1) & (kRing - 1);
+    ring[slot * kBlock + t] = u;
+    const int done = rr - rs + 1;
+    if (rr >= rs && rr < re && ((done & (kStoreRows - 1)) == 0 || rr == re - 1) && colowned) {
+      const int first = rr - ((done - 1) & (kStoreRows - 1));
+#pragma unroll
+      for (int j = 0; j < kStoreRows; j++) {
+        const int r = first + j;
+        if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+      }
+    }
+    {
+      // the operator applied to the new vector on row q = rr - 1 (its rows q - 1 and q are
+      // in the ring since earlier rounds, row q + 1 is this round's value)
+      const double *rq = ring + ((slot + kRing - 1) & (kRing - 1)) * kBlock;
+      const double *rm = ring + ((slot + kRing - 2) & (kRing - 1)) * kBlock;
+      const double us = c > 0 ? rq[tm] : 0.0;
+      const double un = c + 1 < P ? rq[tp] : 0.0;
+      tvs[t] = row_sum(bp[0], bp[1], bp[2], bp[3], bp[4], rm[t], us, rq[t], un, u);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) bp[j] = bcs[j * kBlock + t];
+    __syncthreads();
+    emit_park(rr, o, vi);
+  };
+
+  if (half == 0) {
+    for (int rr = rs - 1; rr <= re; rr += 2) {
+      round0(rr, qa, qb);
+      if (rr + 1 > re) break;
+      round0(rr + 1, qb, qa);
+    }
+  } else {
+    for (int rr = rs - 1; rr <= re; rr += 2) {
+      round1(rr, qa, qb);
+      if (rr + 1 > re) break;
+      round1(rr + 1, qb, qa);
+    }
+  }
+
+  // partial sums in the layout of k_arnoldi_fused; every quantity belongs to one half
+  auto put = [&](int q, double v) __attribute__((always_inline)) {
+    const double tsum = wave_sum(v);
+    if (lane == 0) red[q * 4 + wv] = tsum;
+  };
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    put(kb + k, aT[k]);
+    put(NV + 2 + kb + k, aS[k]);
+  }
+  if (half == 0) {
+    if (NA > NB) {
+      put(NA - 1, aT[NA - 1]);
+      put(NV + 2 + NA - 1, aS[NA - 1]);
+    }
+    put(NV + 1, aTU);
+    put(2 * NV + 3, aUU);
+  } else {
+    put(NV, aT[NB]);
+    put(2 * NV + 2, aS[NB]);
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    double tot = red[threadIdx.x * 4];
+#pragma unroll
+    for (int i = 1; i < 4; i++) tot += red[threadIdx.x * 4 + i];
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
 // The update alone, on the cnt unknowns from k0 on (the whole vector: last step of a
 // cycle; one grid row: the rows a neighbouring rank needs): s_{NV+1} and its squared
 // norm (part[workgroup]).  n: unknowns of the local vector; s_halo: entries in front of
@@ -487,6 +785,23 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV, GEN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
+  }
+  static const int split_from = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : 99;
+  if constexpr (NV >= 12) {
+    if (NV >= split_from) {
+      constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1) * kBlock + (split_store_rows(NV) + 4 + 7) * kBlock +
+                                                (2 * NV + 4) * 4);
+      static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
+      static bool configured2 = false;
+      if (!configured2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_split<NV, GEN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        configured2 = true;
+      }
+      hipLaunchKernelGGL((k_arnoldi_split<NV, GEN>), dim3(geo.nstrips * geo.nbands), dim3(kSplitBlock), lds2, st, geo, b,
+                         gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
+      return;
+    }
   }
   hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN>), dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, gen, V,
                      ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
