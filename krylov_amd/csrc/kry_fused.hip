@@ -335,7 +335,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 // vectors.  Per lane that is half the registers, so two wavefronts fit a SIMD where the
 // kernel above runs with one, and the arithmetic of one overlaps the waiting of the other.
 constexpr int kSplitBlock = 2 * kBlock;
-constexpr int split_store_rows(int nv) { return nv <= 40 ? 16 : 8; }
+constexpr int kSplitFrom = 14;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
+// rows stored together: as many as the LDS left beside the parked vectors holds
+constexpr int split_store_rows(int nv) { return nv <= 34 ? 32 : 16; }
 
 template <int NV, bool GEN>
 __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Bands b, BandGen gen,
@@ -752,6 +754,12 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
 // that (3 per compute unit from 6 earlier vectors on, 2 from 11 on, 1 from 22 on) and the count would
 // leave the last round of workgroups mostly empty, the bands are made taller so that
 // the count fits one round less (2048^2: 567 workgroups = 2.2 rounds of 256 -> 504).
+// first step served by the 512-thread kernel (env KRY_SPLIT_FROM overrides; 99: never)
+int split_from() {
+  static const int v = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : kSplitFrom;
+  return v < 12 ? 12 : v;
+}
+
 FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
   g.rows = rows;
@@ -762,7 +770,8 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   if (nb < 1) nb = 1;
   while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
   // workgroups resident at once: 4 per compute unit up to 128 registers per lane, 3 up to 168, 2 up to 256
-  const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv <= 21 ? 2 : 1)));
+  // (the 512-thread kernel: one per compute unit)
+  const int cap = 256 * (nv >= split_from() ? 1 : (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv <= 21 ? 2 : 1))));
   const int count = g.nstrips * nb, rounds = (count + cap - 1) / cap;
   if (rounds > 1 && count % cap != 0) {
     const int nb2 = (cap * (rounds - 1)) / g.nstrips;
@@ -786,9 +795,8 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  static const int split_from = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : 99;
   if constexpr (NV >= 12) {
-    if (NV >= split_from) {
+    if (NV >= split_from()) {
       constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1) * kBlock + (split_store_rows(NV) + 4 + 7) * kBlock +
                                                 (2 * NV + 4) * 4);
       static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
