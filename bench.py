@@ -198,7 +198,8 @@ def main():
         "mgs_block_full": "k_mgs_block<%d,%d> (Gram-Schmidt sweep: %d projections applied + %d dots)",
         "mgs_block_part": "k_mgs_block<%d,kc> (Gram-Schmidt sweep: %d projections applied + kc < %d dots)",
         "mgs_last": "k_mgs_block<kp,0> (closing Gram-Schmidt sweep of an Arnoldi step: kp <= %d projections applied + norm)",
-        "arnoldi_fused": "k_arnoldi_fused<i> (one-sweep Arnoldi step: operator applied to the newest basis vector, "
+        "arnoldi_fused": "k_arnoldi_fused<i> / k_arnoldi_split<i> (one-sweep Arnoldi step, 256 threads per workgroup up to "
+                         "i = 13, 512 threads whose halves split the basis vectors above: operator applied to the newest basis vector, "
                          "orthogonalised against v_0..v_i, operator applied to the result for all dot products of the "
                          "next step; reads i+1 vectors and the operator -- five bands, or with generated bands the two velocity "
                          "arrays their interior entries are evaluated from --, writes one vector)",

@@ -197,6 +197,13 @@ int kry_gmres_get_mgs_block(const kry_gmres *g);
  * the sweeps are off or unavailable for this solver. */
 int kry_gmres_set_one_sweep(kry_gmres *g, int first_step);
 int kry_gmres_get_one_sweep(const kry_gmres *g);
+/* Tuning knob without a counterpart in the reference: from this step of a cycle on
+ * the one-sweep steps run as workgroups of 512 threads whose halves split the basis
+ * vectors (two wavefronts per SIMD where the 256-thread kernel fits one); every
+ * result bit is the same.  Process-wide; first_step < 0 restores the default (14;
+ * env KRY_SPLIT_FROM), values below 12 mean 12, values beyond the last step: never.
+ * Returns the value in effect. */
+int kry_set_one_sweep_split(int first_step);
 int64_t kry_gmres_size(const kry_gmres *g);
 int kry_gmres_iterations(const kry_gmres *g);
 /* KRY_GMRES_EXTENDED only; no counterpart in the reference, whose solve always

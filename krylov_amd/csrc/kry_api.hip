@@ -831,6 +831,11 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
   return KRY_OK;
 }
 
+int kry_set_one_sweep_split(int first_step) {
+  set_split_from(first_step);
+  return get_split_from();
+}
+
 int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fparts ? g->fused_from : -1; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {

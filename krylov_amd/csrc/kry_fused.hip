@@ -754,10 +754,12 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
 // that (3 per compute unit from 6 earlier vectors on, 2 from 11 on, 1 from 22 on) and the count would
 // leave the last round of workgroups mostly empty, the bands are made taller so that
 // the count fits one round less (2048^2: 567 workgroups = 2.2 rounds of 256 -> 504).
-// first step served by the 512-thread kernel (env KRY_SPLIT_FROM overrides; 99: never)
+// first step served by the 512-thread kernel (set_split_from, else env KRY_SPLIT_FROM, else
+// kSplitFrom; instantiated from 12 on; beyond the last step: never)
+int g_split_from = -1;
 int split_from() {
-  static const int v = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : kSplitFrom;
-  return v < 12 ? 12 : v;
+  if (g_split_from < 0) g_split_from = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : kSplitFrom;
+  return g_split_from < 12 ? 12 : g_split_from;
 }
 
 FusedGeom fused_geom(int rows, int P, int nv) {
@@ -866,6 +868,9 @@ struct FusedTable<-1> {
 };
 
 }  // namespace
+
+void set_split_from(int first_step) { g_split_from = first_step < 0 ? kSplitFrom : first_step; }
+int get_split_from() { return split_from(); }
 
 int fused_parts(int rows, int cols) {
   const FusedGeom g = fused_geom(rows, cols, 0);  // the largest count over all steps

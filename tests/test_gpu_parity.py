@@ -399,6 +399,38 @@ def test_generated_bands_bit_identical(ctx, name, shape, m):
     assert np.array_equal(H1, H0, equal_nan=True)
 
 
+@pytest.mark.parametrize("name,shape,m", [("s_iso", (300, 260), 50), ("s_iso", (40, 30), 35), ("s_iso", (5, 700), 50),
+                                          ("prob1", None, 30), ("s_iso", (700, 250), 24), ("s_iso", (33, 253), 14),
+                                          ("s_iso", (1100, 520), 48), ("s_iso", (64, 1030), 41)])
+def test_split_sweep_kernel_bit_identical(ctx, name, shape, m):
+    """The 512-thread variant of the one-sweep kernel (the two halves of a
+    workgroup split the basis vectors; the update chain continues from one
+    half to the other in the same order, the partial sums are reduced in the
+    same order) reproduces every bit of the 256-thread kernel: two implicit
+    steps, generated and stored bands, every instantiation from 12 vectors
+    on, one strip and several strips, bands of rows that do and do not divide
+    the grid."""
+    from krylov_amd import capi
+    L = capi.lib()
+    cfg = problems.prob1() if name == "prob1" else getattr(problems, name)(*shape)
+    try:
+        runs = {}
+        for first in (12, 10 ** 6):
+            assert L.kry_set_one_sweep_split(first) == max(first, 12)
+            for gen in (True, False):
+                dev = host.ImplicitEuler(ctx, **cfg, m=m)
+                dev.set_generated_bands(gen)
+                d = [dev.timestep(0.25) for _ in range(2)]
+                runs[(first, gen)] = (d, dev.field(0), dev.solver().hessenberg_matrix())
+        for gen in (True, False):
+            (d1, T1, H1), (d0, T0, H0) = runs[(12, gen)], runs[(10 ** 6, gen)]
+            assert d1 == d0
+            assert np.array_equal(T1, T0, equal_nan=True)
+            assert np.array_equal(H1, H0, equal_nan=True)
+    finally:
+        L.kry_set_one_sweep_split(-1)
+
+
 def test_one_sweep_needs_a_grid_stencil(ctx, oracle):
     """A 5-band operator that couples the last entry of one grid row with the
     first entry of the next is not a 2-D stencil: the solver keeps to the chain

@@ -21,7 +21,7 @@ import sys
 def family(name):
     if "k_spmv_stencil" in name:
         return "spmv_dots"
-    if "k_arnoldi_fused" in name:
+    if "k_arnoldi_fused" in name or "k_arnoldi_split" in name:
         return "arnoldi_fused"
     m = re.search(r"k_mgs_block<(\d+), (\d+), (true|false)", name)
     if m:
