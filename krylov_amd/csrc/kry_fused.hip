@@ -773,7 +773,7 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
   // workgroups resident at once: 4 per compute unit up to 128 registers per lane, 3 up to 168, 2 up to 256
   // (the 512-thread kernel: one per compute unit)
-  const int cap = 256 * (nv >= split_from() ? 1 : (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv <= 21 ? 2 : 1))));
+  const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv <= 21 && nv < split_from() ? 2 : 1)));
   const int count = g.nstrips * nb, rounds = (count + cap - 1) / cap;
   if (rounds > 1 && count % cap != 0) {
     const int nb2 = (cap * (rounds - 1)) / g.nstrips;
@@ -797,7 +797,8 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  if constexpr (NV >= 12) {
+  // (with stored bands the 512-thread kernel needs scratch from 47 earlier vectors on and is slower there)
+  if constexpr (NV >= 12 && (GEN || NV <= 46)) {
     if (NV >= split_from()) {
       constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1) * kBlock + (split_store_rows(NV) + 4 + 7) * kBlock +
                                                 (2 * NV + 4) * 4);
