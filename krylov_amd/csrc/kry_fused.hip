@@ -749,11 +749,6 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
     dst[i] = src[i] / sg;
 }
 
-// Strips and bands for step nv.  About four workgroups per compute unit, bands of at
-// least 32 rows; when the kernel's registers and LDS allow fewer resident workgroups than
-// that (3 per compute unit from 6 earlier vectors on, 2 from 11 on, 1 from 22 on) and the count would
-// leave the last round of workgroups mostly empty, the bands are made taller so that
-// the count fits one round less (2048^2: 567 workgroups = 2.2 rounds of 256 -> 504).
 // first step served by the 512-thread kernel (set_split_from, else env KRY_SPLIT_FROM, else
 // kSplitFrom; instantiated from 12 on; beyond the last step: never)
 int g_split_from = -1;
@@ -762,24 +757,37 @@ int split_from() {
   return g_split_from < 12 ? 12 : g_split_from;
 }
 
+// Strips and bands for step nv.  A band of R rows costs about kBandOverhead rows more than
+// its share (halo rows at either end, filling the request window, the final reduction), and
+// workgroups run in rounds of `cap` (the number resident at once: 4 per compute unit up to 128
+// registers per lane, 3 up to 168, 2 up to 256, 1 for the 512-thread kernel): among the band
+// counts that fill one to four rounds, the one with the best product of occupancy and
+// useful share is taken (8192^2: 31 bands in four rounds; 2048^2 and the row blocks of
+// eight ranks: fewer, taller bands).  At most 1024 workgroups (the partial-sum buffers).
+// The choice depends on nv alone, not on which kernel variant a knob selects.
+constexpr int kBandOverhead = 6;
 FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
   g.rows = rows;
   g.P = P;
   g.nstrips = (P + kStripMax - 1) / kStripMax;
   g.W = (P + g.nstrips - 1) / g.nstrips;
-  int nb = (4 * 256) / g.nstrips;
-  if (nb < 1) nb = 1;
-  while (nb > 1 && (rows + nb - 1) / nb < 32) nb--;
-  // workgroups resident at once: 4 per compute unit up to 128 registers per lane, 3 up to 168, 2 up to 256
-  // (the 512-thread kernel: one per compute unit)
-  const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv <= 21 && nv < split_from() ? 2 : 1)));
-  const int count = g.nstrips * nb, rounds = (count + cap - 1) / cap;
-  if (rounds > 1 && count % cap != 0) {
-    const int nb2 = (cap * (rounds - 1)) / g.nstrips;
-    if (nb2 >= 1 && (double)(g.nstrips * nb2) / (rounds - 1) > (double)count / rounds) nb = nb2;
+  const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv < kSplitFrom ? 2 : 1)));
+  int best_nb = 1;
+  double best = -1.0;
+  for (int r = 1; r <= 4 && cap * r <= 1024; r++) {
+    int nb = (cap * r) / g.nstrips;
+    if (nb > rows / 32) nb = rows / 32;  // bands of at least 32 rows
+    if (nb < 1) nb = 1;
+    const int R = (rows + nb - 1) / nb, nbands = (rows + R - 1) / R;
+    const int count = g.nstrips * nbands, rounds = (count + cap - 1) / cap;
+    const double score = (double)count / ((double)cap * rounds) * (double)R / (double)(R + kBandOverhead);
+    if (score > best) {
+      best = score;
+      best_nb = nb;
+    }
   }
-  g.R = (rows + nb - 1) / nb;
+  g.R = (rows + best_nb - 1) / best_nb;
   g.nbands = (rows + g.R - 1) / g.R;
   return g;
 }
@@ -874,8 +882,12 @@ void set_split_from(int first_step) { g_split_from = first_step < 0 ? kSplitFrom
 int get_split_from() { return split_from(); }
 
 int fused_parts(int rows, int cols) {
-  const FusedGeom g = fused_geom(rows, cols, 0);  // the largest count over all steps
-  return g.nstrips * g.nbands;
+  int most = 0;  // the largest count over all steps
+  for (int nv = 0; nv < kFusedMaxM; nv++) {
+    const FusedGeom g = fused_geom(rows, cols, nv);
+    if (g.nstrips * g.nbands > most) most = g.nstrips * g.nbands;
+  }
+  return most;
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
