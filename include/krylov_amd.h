@@ -277,8 +277,9 @@ int kry_ie_init_offdiag(kry_ie *ie);
  * one diagonal value (:294-302).  With on != 0 (the default) the one-sweep Arnoldi
  * steps evaluate those entries from a copy of u and v taken by kry_ie_init_offdiag
  * (same operations, same bits) instead of reading five stored bands: two streamed
- * arrays instead of five.  Results are bit-identical either way; ghost rows and
- * columns always read the stored bands.  get: 1 when the evaluation is in use. */
+ * arrays instead of five; the entries of ghost rows and columns (a 1 towards the
+ * interior, the diagonal 2w - 1 of their side, :304-337) follow from their position.
+ * Results are bit-identical either way.  get: 1 when the evaluation is in use. */
 int kry_ie_set_generated_bands(kry_ie *ie, int on);
 int kry_ie_get_generated_bands(const kry_ie *ie);
 /* ImplicitEuler::assemble_system, include/time_disc.hpp:291-339 */

@@ -1344,7 +1344,7 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
     launches[KRY_K_SPMV] += 1;
     // the operator as a sweep reads it: five bands, or the two velocity arrays its interior
-    // entries are evaluated from (the stored bands are then read on ghost rows and columns only)
+    // entries are evaluated from (no stored band is read then)
     const double opf = op->has_gen && op->use_gen ? 2.0 * N : opb;
     for (int i = i0; i < m - 1; i++) {
       // read: the i + 1 stored vectors, operator; written: the new vector

@@ -36,6 +36,11 @@
 // recomputing them (u_halo); the neighbours' rows of s_i are in the halo of
 // slot i since the step before.
 //
+// Two kernels do this: k_arnoldi_fused (256 threads per workgroup, every step) and, from
+// kSplitFrom earlier vectors on, k_arnoldi_split (512 threads whose two halves split the
+// basis vectors, so that two wavefronts fit a SIMD where the first kernel runs with one);
+// both produce the same bits.
+//
 // Requirements, checked by the host: 5-band operator whose couplings across
 // the ends of a grid row (band s in column 0, band n in the last column) are
 // zero, m <= kFusedMaxM.

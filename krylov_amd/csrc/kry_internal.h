@@ -30,7 +30,7 @@ struct Bands {
 // are functions of the velocities next to it at the time the off-diagonals were formed,
 // and all interior cells share one diagonal value.  A kernel that holds a recipe
 // evaluates those entries (same operations as k_offdiag, hence the same bits) instead
-// of reading them, and reads the stored bands only on ghost rows and columns.
+// of reading them; the entries of ghost rows and columns follow from their position.
 struct BandGen {
   const double *u = nullptr, *v = nullptr;  // velocity snapshots, laid out like the fields (halo row in front and behind)
   const double *cdiag = nullptr;            // the diagonal entry of one interior cell (any entry when the rank owns none)
