@@ -342,7 +342,10 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 constexpr int kSplitBlock = 2 * kBlock;
 constexpr int kSplitFrom = 14;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
 // rows stored together: as many as the LDS left beside the parked vectors holds
-constexpr int split_store_rows(int nv) { return nv <= 34 ? 32 : 16; }
+constexpr int split_store_rows(int nv) { return nv <= 42 ? 32 : 16; }
+// Vectors per half whose parked values wait in registers instead of LDS: where registers
+// are left, that buys the LDS for 32-row bursts up to 42 earlier vectors.
+constexpr int split_park_regs(int nv) { return nv >= 35 && nv <= 42 ? 4 : 0; }
 
 template <int NV, bool GEN>
 __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Bands b, BandGen gen,
@@ -358,9 +361,13 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   constexpr int NA = (NV + 1) / 2, NB = NV - NA;  // vectors of half 0: [0, NA), of half 1: [NA, NV) and s_NV
   static_assert(NB >= 1, "both halves need a vector");
   constexpr int kStoreRows = split_store_rows(NV), kRing = kStoreRows;
+  constexpr int PK = split_park_regs(NV);  // vectors per half parked in registers
+  static_assert(PK <= NB, "a half parks its own vectors");
   extern __shared__ double lds[];
-  double *keep = lds;                               // (NV + 1) x kBlock: s_k of the previous row
-  double *ring = keep + (size_t)(NV + 1) * kBlock;  // kRing x kBlock: the last rows of u
+  // s_k of the previous row: (NV + 1 - 2 PK) x kBlock -- half 0's vectors PK .. NA-1, half 1's
+  // vectors PK .. NB-1, then s_NV
+  double *keep = lds;
+  double *ring = keep + (size_t)(NV + 1 - 2 * PK) * kBlock;  // kRing x kBlock: the last rows of u
   double *sring = ring + kRing * kBlock;            // 4 x kBlock: rows rr-1 .. rr+2 of s_NV
   double *xa = sring + 4 * kBlock;                  // kBlock: half 0's value of the update chain
   double *bcs = xa + kBlock;                        // 5 x kBlock: operator coefficients of row rr
@@ -459,6 +466,12 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   __syncthreads();
 
   // dot products of row q = rr - 1 from the parked values, then this row's values are parked
+  double pk[PK > 0 ? PK : 1];  // this half's first PK vectors of the previous row
+#pragma unroll
+  for (int k = 0; k < (PK > 0 ? PK : 1); k++) pk[k] = 0.0;
+  // LDS row of this half's k-th vector (k >= PK)
+  const int krow = (half ? NA - PK : 0) - PK;
+  constexpr int kRowS = NV - 2 * PK;  // ... and of s_NV
   auto emit_park = [&](const int rr, Req &o, const double vi) __attribute__((always_inline)) {
     const int q = rr - 1;
     const int slot = (rr - rs + 1) & (kRing - 1);
@@ -467,30 +480,35 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
       const double uq = ring[((slot + kRing - 1) & (kRing - 1)) * kBlock + t];
 #pragma unroll
       for (int k = 0; k < NB; k++) {
-        const double sk = keep[(kb + k) * kBlock + t];
+        const double sk = k < PK ? pk[k] : keep[(krow + k) * kBlock + t];
         aT[k] = fma(sk, tv, aT[k]);
         aS[k] = fma(sk, uq, aS[k]);
       }
       if (half == 0) {
         if (NA > NB) {
-          const double sk = keep[(NA - 1) * kBlock + t];
+          const double sk = keep[(krow + NA - 1) * kBlock + t];
           aT[NA - 1] = fma(sk, tv, aT[NA - 1]);
           aS[NA - 1] = fma(sk, uq, aS[NA - 1]);
         }
         aTU = fma(uq, tv, aTU);
         aUU = fma(uq, uq, aUU);
       } else {
-        const double sk = keep[NV * kBlock + t];
+        const double sk = keep[kRowS * kBlock + t];
         aT[NB] = fma(sk, tv, aT[NB]);
         aS[NB] = fma(sk, uq, aS[NB]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < NB; k++) keep[(kb + k) * kBlock + t] = o.v[k];
+    for (int k = 0; k < NB; k++) {
+      if (k < PK)
+        pk[k] = o.v[k];
+      else
+        keep[(krow + k) * kBlock + t] = o.v[k];
+    }
     if (half == 0) {
-      if (NA > NB) keep[(NA - 1) * kBlock + t] = o.v[NA - 1];
+      if (NA > NB) keep[(krow + NA - 1) * kBlock + t] = o.v[NA - 1];
     } else {
-      keep[NV * kBlock + t] = vi;
+      keep[kRowS * kBlock + t] = vi;
     }
   };
 
@@ -813,8 +831,8 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
   // (with stored bands the 512-thread kernel needs scratch from 47 earlier vectors on and is slower there)
   if constexpr (NV >= 12 && (GEN || NV <= 46)) {
     if (NV >= split_from()) {
-      constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1) * kBlock + (split_store_rows(NV) + 4 + 7) * kBlock +
-                                                (2 * NV + 4) * 4);
+      constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1 - 2 * split_park_regs(NV)) * kBlock +
+                                                (split_store_rows(NV) + 4 + 7) * kBlock + (2 * NV + 4) * 4);
       static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
       static bool configured2 = false;
       if (!configured2) {
