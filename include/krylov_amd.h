@@ -285,8 +285,18 @@ int kry_ie_get_generated_bands(const kry_ie *ie);
 /* ImplicitEuler::assemble_system, include/time_disc.hpp:291-339 */
 int kry_ie_assemble_system(kry_ie *ie, double dt);
 /* ImplicitEuler::timestep, include/time_disc.hpp:277-289.  *max_delta is the
- * largest |delta| over interior cells (NaN if any of them is NaN). */
+ * reference's value: the fold max_delta = std::max(|delta|, max_delta) over the
+ * interior cells in (i, j) order (:284), whose comparisons are all false for a
+ * NaN, i.e. the largest |delta| over the cells BEHIND the last NaN cell, and NaN
+ * only if the last interior cell is NaN. */
 int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta);
+/* The second half of that step on its own (include/time_disc.hpp:281-286) for a
+ * caller-supplied delta: T += delta on interior cells (ghost entries are
+ * ignored, as in the reference) and the same maximum.  delta_local: the owned
+ * rows in padded layout, kry_ie_local_size doubles; it replaces the solver's
+ * previous result.  Time does not advance.  Collective on a row-block
+ * decomposition. */
+int kry_ie_apply_delta(kry_ie *ie, const double *delta_local, double *max_delta);
 /* The same step queued without reading max|delta| back (for back-to-back
  * steps with time-independent boundary values); fetch with kry_ie_last_max_delta. */
 int kry_ie_timestep_async(kry_ie *ie, double dt);

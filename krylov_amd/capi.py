@@ -15,6 +15,7 @@ _vp = C.c_void_p
 _vpp = C.POINTER(C.c_void_p)
 
 OK = 0
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = 1, 2, 3, 4
 FIELD_T, FIELD_U, FIELD_V = 0, 1, 2
 BOTTOM, TOP, LEFT, RIGHT = 0, 1, 2, 3
 GMRES_PLAIN, GMRES_TDP, GMRES_FIXED_PRECOND, GMRES_EXTENDED = 0, 1, 2, 8
@@ -86,6 +87,7 @@ SIGNATURES = {
     "kry_ie_get_generated_bands": (C.c_int, [_vp]),
     "kry_ie_assemble_system": (C.c_int, [_vp, C.c_double]),
     "kry_ie_timestep": (C.c_int, [_vp, C.c_double, _dp]),
+    "kry_ie_apply_delta": (C.c_int, [_vp, _dp, _dp]),
     "kry_ie_timestep_async": (C.c_int, [_vp, C.c_double]),
     "kry_ie_last_max_delta": (C.c_int, [_vp, _dp]),
     "kry_ie_timestep_approx_fact": (C.c_int, [_vp, C.c_double, _dp]),

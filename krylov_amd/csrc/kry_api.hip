@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -22,6 +23,12 @@
 using namespace kry;
 
 static thread_local std::string g_err;
+
+// Bumped by every setter that changes which kernels a solve launches or how (links per
+// sweep, hand-over to the one-sweep steps, generated bands, the 512-thread hand-over): a
+// captured step is recorded again when the count differs from the one it was captured at.
+static std::atomic<uint64_t> g_config_epoch{1};
+static void config_changed() { g_config_epoch.fetch_add(1, std::memory_order_relaxed); }
 
 static int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -254,6 +261,7 @@ struct kry_ie {
   bool use_graph = false;
   hipGraphExec_t graph_exec = nullptr;
   double graph_dt = 0.0;
+  uint64_t graph_epoch = 0;  // g_config_epoch at capture
   bool whole() const { return g.row0 == 0 && g.rows == g.cx + 2; }
 };
 
@@ -528,7 +536,10 @@ extern "C" int kry_ctx_comm_selftest(kry_ctx *ctx) {
 }
 
 static int launch_ok(const char *what) {
-  hipError_t e = hipGetLastError();
+  const char *prep = "";
+  hipError_t e = take_launch_failure(&prep);
+  if (e != hipSuccess) return fail(KRY_ERR_HIP, "%s could not be set in %s: %s", prep, what, hipGetErrorString(e));
+  e = hipGetLastError();
   if (e != hipSuccess) return fail(KRY_ERR_HIP, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
   return KRY_OK;
 }
@@ -814,6 +825,7 @@ int kry_gmres_set_mgs_block(kry_gmres *g, int k) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
   if (!mgs_block_supported(k)) return fail(KRY_ERR_INVALID, "block size must be one of 1, 2, 3, 4, 8, 16, 32");
   g->kblock = k;
+  config_changed();
   return KRY_OK;
 }
 
@@ -821,6 +833,7 @@ int kry_gmres_get_mgs_block(const kry_gmres *g) { return g ? g->kblock : 0; }
 
 int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
+  config_changed();
   if (first_step < 0) {
     g->fused_from = -1;
     return KRY_OK;
@@ -832,11 +845,21 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
 }
 
 int kry_set_one_sweep_split(int first_step) {
+  config_changed();
   set_split_from(first_step);
   return get_split_from();
 }
 
-int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fparts ? g->fused_from : -1; }
+// The hand-over step in effect.  The first sweep recovers its coefficients from the Gram
+// matrix of ALL vectors stored so far, and the chain only carries the Gram entries of
+// vectors that share a group of kblock links: the hand-over happens while the basis is
+// still within the chain's first group.
+static int fused_first(const kry_gmres *g) {
+  if (g->fused_from < 0) return -1;
+  return g->fused_from < g->kblock - 1 ? g->fused_from : g->kblock - 1;
+}
+
+int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fparts ? fused_first(g) : -1; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
@@ -924,6 +947,9 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   }
   g->nvec = 1;
   g->scaled = false;
+  // every vector starts a cycle normalised; the one-sweep steps overwrite the entries of
+  // the slots they fill (never predicated: a monitored solve may stop before they run)
+  if (g->fsigma) launch_fill(st, g->fsigma, 1.0, kFusedCoef);
   return launch_ok("initial_subspace");
 }
 
@@ -1026,13 +1052,14 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       launch_scale_from(st, g->w, basis(g, 0), pin, np, n, g->beta);
       g->nvec = 1;
       g->scaled = false;
+      if (g->fsigma) launch_fill(st, g->fsigma, 1.0, kFusedCoef);
     }
     {
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
       launch_ext_begin(st, g->beta, g->ext, gv, m, cycle == 0, g->rtol);
     }
     HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(m + 1) * m, st));
-    const int chain_steps = fused_usable(g, op) ? g->fused_from : m;
+    const int chain_steps = fused_usable(g, op) ? fused_first(g) : m;
     for (int j = 0; j < chain_steps; j++) {
       KCHK(arnoldi_async(g, op));
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
@@ -1098,7 +1125,7 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   double *R = g->R, *rot_c = ext ? R + (int64_t)(g->m + 1) * g->m : nullptr, *rot_s = ext ? rot_c + g->m : nullptr,
          *gv = ext ? rot_s + g->m : nullptr;
   hipStream_t st = g->ctx->stream;
-  const int m = g->m, i0 = g->fused_from;
+  const int m = g->m, i0 = fused_first(g);
   const int64_t n = g->n;
   const int64_t P = op->cols;
   const bool ranks = g->ctx->nranks > 1;
@@ -1158,7 +1185,7 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   KCHK(initial_subspace_async(g, b_dev));
   HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
   if (fused_usable(g, op)) {
-    for (int i = 0; i < g->fused_from; i++) KCHK(arnoldi_async(g, op));
+    for (int i = 0; i < fused_first(g); i++) KCHK(arnoldi_async(g, op));
     KCHK(fused_steps_async(g, op));
   } else {
     for (int i = 0; i < g->m; i++) KCHK(arnoldi_async(g, op));
@@ -1323,7 +1350,7 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
   // bytes of the operator itself: five bands, or CSR values + indices + row pointers
   const double opb = op->kind == 0 ? 5.0 * N : 12.0 * (double)op->nnz + 8.0 * (double)(op->n + 1);
   const bool fused = fused_usable(g, op);
-  const int chain_steps = fused ? g->fused_from : m;
+  const int chain_steps = fused ? fused_first(g) : m;
   for (int j = 0; j < chain_steps; j++) {
     const int nv = j + 1;
     int kp = nv < K ? nv : K;
@@ -1340,7 +1367,7 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     launches[KRY_K_MGS_LAST] += 1;
   }
   if (fused) {
-    const int i0 = g->fused_from;
+    const int i0 = fused_first(g);
     bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
     launches[KRY_K_SPMV] += 1;
     // the operator as a sweep reads it: five bands, or the two velocity arrays its interior
@@ -1458,8 +1485,8 @@ int kry_ie_create_slab(kry_ctx *ctx, double c1x, double c1y, double c2x, double 
   if (st == KRY_OK && hipHostMalloc((void **)&ie->bcvals_h, sizeof(double) * nbc) != hipSuccess) st = fail(KRY_ERR_HIP, "pinned alloc failed");
   if (st == KRY_OK) memset(ie->bcvals_h, 0, sizeof(double) * nbc);
   if (st == KRY_OK) st = dev_alloc(&ie->wrap, 3 * cy);
-  if (st == KRY_OK) st = dev_alloc(&ie->parts, kMaxParts);
-  if (st == KRY_OK) st = dev_alloc(&ie->maxd, 1);
+  if (st == KRY_OK) st = dev_alloc(&ie->parts, 2 * kMaxParts);
+  if (st == KRY_OK) st = dev_alloc(&ie->maxd, 4);
   if (st == KRY_OK && hipHostMalloc((void **)&ie->maxd_h, sizeof(double)) != hipSuccess) st = fail(KRY_ERR_HIP, "pinned alloc failed");
   if (st == KRY_OK) {
     kry_op *op = new kry_op;
@@ -1549,24 +1576,40 @@ static int ie_assemble_async(kry_ie *ie, double dt, bool force_upload) {
   return launch_ok("assemble_system");
 }
 
+// Second half of ImplicitEuler::timestep (include/time_disc.hpp:281-286): T += delta on
+// interior cells and the returned maximum (std::max fold in cell order, see k_update_max),
+// for the delta in the solver's result vector; queues the copy of the maximum to the host.
+static int ie_update_async(kry_ie *ie) {
+  hipStream_t st = ie->ctx->stream;
+  {
+    ScopedKernelTimer t(ie->ctx, KRY_K_ASSEMBLY);
+    int np = 0;
+    launch_update_max(st, ie->g, ie->fld[0], ie->solver->vars, ie->parts, &np);
+    if (ie->ctx->nranks == 1) {
+      launch_max_fold(st, ie->g, ie->solver->vars, ie->parts, np, ie->maxd, 7);
+    } else {
+      // cell order runs through the ranks' row blocks: every rank needs the last NaN
+      // position of the whole mesh before it can take its share of the maximum
+      launch_max_fold(st, ie->g, ie->solver->vars, ie->parts, np, ie->maxd, 1);
+      KCHK(comm_allreduce(ie->ctx, ie->maxd + 1, 2, KRY_REDUCE_MAX));
+      launch_max_fold(st, ie->g, ie->solver->vars, ie->parts, np, ie->maxd, 2);
+      KCHK(comm_allreduce(ie->ctx, ie->maxd, 1, KRY_REDUCE_MAX));
+      launch_max_fold(st, ie->g, ie->solver->vars, ie->parts, np, ie->maxd, 4);
+    }
+  }
+  KCHK(launch_ok("timestep"));
+  HIPCHK(hipMemcpyAsync(ie->maxd_h, ie->maxd, sizeof(double), hipMemcpyDeviceToHost, st));
+  return KRY_OK;
+}
+
 // everything of ImplicitEuler::timestep that runs on the device
 static int ie_step_body(kry_ie *ie, double dt, bool force_upload) {
-  hipStream_t st = ie->ctx->stream;
   {
     ScopedKernelTimer t(ie->ctx, KRY_K_ASSEMBLY);
     KCHK(ie_assemble_async(ie, dt, force_upload));
   }
   KCHK(solve_async(ie->solver, ie->op, ie->rhs, nullptr));
-  {
-    ScopedKernelTimer t(ie->ctx, KRY_K_ASSEMBLY);
-    int np = 0;
-    launch_update_max(st, ie->g, ie->fld[0], ie->solver->vars, ie->parts, &np);
-    launch_max_final(st, ie->parts, np, ie->maxd);
-  }
-  KCHK(comm_allreduce(ie->ctx, ie->maxd, 1, KRY_REDUCE_MAX));
-  KCHK(launch_ok("timestep"));
-  HIPCHK(hipMemcpyAsync(ie->maxd_h, ie->maxd, sizeof(double), hipMemcpyDeviceToHost, st));
-  return KRY_OK;
+  return ie_update_async(ie);
 }
 
 static int ie_step_async(kry_ie *ie, double dt) {
@@ -1576,7 +1619,8 @@ static int ie_step_async(kry_ie *ie, double dt) {
   if (!ie->use_graph || (ie->ctx->nranks > 1 && !ie->ctx->nccl) || (ie->solver->flags & KRY_GMRES_EXTENDED)) {
     KCHK(ie_step_body(ie, dt, false));
   } else {
-    if (!ie->graph_exec || ie->graph_dt != dt) {
+    const uint64_t epoch = g_config_epoch.load(std::memory_order_relaxed);
+    if (!ie->graph_exec || ie->graph_dt != dt || ie->graph_epoch != epoch) {
       if (ie->graph_exec) {
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGraphExecDestroy(ie->graph_exec));
@@ -1598,6 +1642,7 @@ static int ie_step_async(kry_ie *ie, double dt) {
       (void)hipGraphDestroy(graph);
       if (e != hipSuccess) return fail(KRY_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
       ie->graph_dt = dt;
+      ie->graph_epoch = epoch;
     }
     ie->bc_dirty = false;  // the graph always re-uploads the staged boundary values
     HIPCHK(hipGraphLaunch(ie->graph_exec, st));
@@ -1677,6 +1722,7 @@ int kry_ie_init_offdiag(kry_ie *ie) {
 
 int kry_ie_set_generated_bands(kry_ie *ie, int on) {
   if (!ie) return fail(KRY_ERR_INVALID, "NULL argument");
+  config_changed();
   ie->op->use_gen = on != 0;
   return KRY_OK;
 }
@@ -1716,6 +1762,18 @@ int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta) {
   return KRY_OK;
 }
 
+int kry_ie_apply_delta(kry_ie *ie, const double *delta_local, double *max_delta) {
+  if (!ie || !delta_local) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (!ie->solver) return fail(KRY_ERR_STATE, "step object was created without a solver");
+  HIPCHK(hipSetDevice(ie->ctx->device));
+  KCHK(ie_wait(ie));
+  HIPCHK(hipMemcpyAsync(ie->solver->vars, delta_local, sizeof(double) * ie->nloc, hipMemcpyHostToDevice, ie->ctx->stream));
+  KCHK(ie_update_async(ie));
+  HIPCHK(hipStreamSynchronize(ie->ctx->stream));
+  if (max_delta) *max_delta = *ie->maxd_h;
+  return KRY_OK;
+}
+
 // ImplicitEulerApproxFact::timestep, include/time_disc.hpp:443-485.  The five
 // band arrays and the right-hand-side array of the step object serve as the
 // line systems' storage (lo, di, up, pivots, normalised upper diagonal,
@@ -1736,7 +1794,7 @@ int kry_ie_timestep_approx_fact(kry_ie *ie, double dt, double *max_delta) {
   launch_tdp_apply(st, lo, dd, ud, ie->rhs, ie->rhs, lines, L);
   int np = 0;
   launch_af_sweep_x(st, ie->g, ie->bc, dt, ie->fld[0], ie->fld[1], ie->rhs, dd, ud, ie->parts, &np);
-  launch_max_final(st, ie->parts, np, ie->maxd);
+  launch_af_max_final(st, ie->g, ie->parts, np, ie->maxd);
   KCHK(launch_ok("approximate factorisation step"));
   HIPCHK(hipMemcpyAsync(ie->maxd_h, ie->maxd, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

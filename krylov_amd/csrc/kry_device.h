@@ -39,11 +39,6 @@ __device__ __forceinline__ double sum_parts(const double *__restrict__ part, int
   return block_sum(a, s);
 }
 
-__device__ __forceinline__ double nan_max(double a, double b) {
-  // max that keeps a NaN once one has been seen
-  return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b);
-}
-
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ d2 ld_nt(const d2 *p) { return __builtin_nontemporal_load(p); }

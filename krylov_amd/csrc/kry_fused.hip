@@ -46,6 +46,8 @@
 // zero, m <= kFusedMaxM.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kry_device.h"
 
 namespace kry {
@@ -774,10 +776,31 @@ __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ s
 
 // first step served by the 512-thread kernel (set_split_from, else env KRY_SPLIT_FROM, else
 // kSplitFrom; instantiated from 12 on; beyond the last step: never)
-int g_split_from = -1;
+std::atomic<int> g_split_from{-1};
 int split_from() {
-  if (g_split_from < 0) g_split_from = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : kSplitFrom;
-  return g_split_from < 12 ? 12 : g_split_from;
+  int v = g_split_from.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = getenv("KRY_SPLIT_FROM") ? atoi(getenv("KRY_SPLIT_FROM")) : kSplitFrom;
+    g_split_from.store(v, std::memory_order_relaxed);
+  }
+  return v < 12 ? 12 : v;
+}
+
+// A sweep that needs more than 64 KB of LDS has to be allowed to, once per kernel and
+// DEVICE (a process may hold contexts on several).  `done` has one bit per device id.
+template <typename K>
+void allow_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done, const char *what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;  // beyond 63: set it every time
+  const uint64_t bit = 1ull << dev;
+  if (dev < 63 && (done.load(std::memory_order_acquire) & bit)) return;
+  const hipError_t e =
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    note_launch_failure(e, what);
+    return;
+  }
+  done.fetch_or(bit, std::memory_order_release);
 }
 
 // Strips and bands for step nv.  A band of R rows costs about kBandOverhead rows more than
@@ -822,24 +845,16 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
   constexpr size_t lds =
       sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 4) * (kBlock / 64));
   static_assert(lds <= 160 * 1024, "LDS of one compute unit");
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_fused<NV, GEN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = true;
-  }
+  static std::atomic<uint64_t> configured{0};
+  allow_lds(&k_arnoldi_fused<NV, GEN>, lds, configured, "LDS size of the one-sweep kernel");
   // (with stored bands the 512-thread kernel needs scratch from 47 earlier vectors on and is slower there)
   if constexpr (NV >= 12 && (GEN || NV <= 46)) {
     if (NV >= split_from()) {
       constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1 - 2 * split_park_regs(NV)) * kBlock +
                                                 (split_store_rows(NV) + 4 + 7) * kBlock + (2 * NV + 4) * 4);
       static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
-      static bool configured2 = false;
-      if (!configured2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_split<NV, GEN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        configured2 = true;
-      }
+      static std::atomic<uint64_t> configured2{0};
+      allow_lds(&k_arnoldi_split<NV, GEN>, lds2, configured2, "LDS size of the 512-thread one-sweep kernel");
       hipLaunchKernelGGL((k_arnoldi_split<NV, GEN>), dim3(geo.nstrips * geo.nbands), dim3(kSplitBlock), lds2, st, geo, b,
                          gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
       return;
@@ -901,7 +916,7 @@ struct FusedTable<-1> {
 
 }  // namespace
 
-void set_split_from(int first_step) { g_split_from = first_step < 0 ? kSplitFrom : first_step; }
+void set_split_from(int first_step) { g_split_from.store(first_step < 0 ? kSplitFrom : first_step); }
 int get_split_from() { return split_from(); }
 
 int fused_parts(int rows, int cols) {

@@ -70,6 +70,12 @@ class LaunchPredicate {
   const int *saved_;
 };
 
+// Launchers return nothing; one that cannot prepare its launch (e.g. the device refuses the
+// LDS size a kernel asks for) records the first such failure of the calling thread here,
+// and the entry point that queued the work reports it (take: returns it and clears it).
+void note_launch_failure(hipError_t e, const char *what);
+hipError_t take_launch_failure(const char **what);
+
 // ---- launchers (all asynchronous on `st`) ---------------------------------
 int grid_for(int64_t items);
 
@@ -193,10 +199,18 @@ void launch_offdiag(hipStream_t st, const IeGeom &g, const double *u, const doub
 void launch_assemble(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,
                      const double *u, const double *v, double *bw, double *bs, double *bcn,
                      double *bn, double *be, double *rhs);
-// T += delta on interior cells; part = per-block max |delta| (NaN sticky)
+// T += delta on interior cells; part (2 * nparts doubles) = per workgroup the largest
+// |delta| that is not NaN and the last position of a NaN
 void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double *delta,
                        double *part, int *nparts);
-void launch_max_final(hipStream_t st, const double *part, int nparts, double *out);
+// The reference's max_delta (std::max fold in cell order: the maximum behind the last NaN
+// cell, NaN if the last cell is NaN) from those partial results; scal = {result, last NaN
+// position, largest |delta| that is not NaN}; phases: bit 0 collapse the partial results,
+// bit 1 the maximum behind the last NaN position, bit 2 the NaN case (see k_max_fold)
+void launch_max_fold(hipStream_t st, const IeGeom &g, const double *delta, const double *part, int nparts,
+                     double *scal, int phases);
+// The same fold for the approximate-factorisation step from k_af_sweep_x's summaries.
+void launch_af_max_final(hipStream_t st, const IeGeom &g, const double *part, int nparts, double *out);
 // Approximate factorisation: y-direction line systems (coefficients and right-hand
 // side, padded layout), and the x-direction sweep with the state update.
 void launch_af_rows_y(hipStream_t st, const IeGeom &g, const IeBc &bc, double dt, const double *T,

@@ -28,6 +28,26 @@ LaunchPredicate::LaunchPredicate(const int *stop) : saved_(t_stop) { t_stop = st
 LaunchPredicate::~LaunchPredicate() { t_stop = saved_; }
 const int *launch_predicate_current() { return t_stop; }
 
+// A failure met while preparing a launch (launchers return nothing): kept per thread
+// until the entry point that queued the work asks for it.
+static thread_local hipError_t t_failure = hipSuccess;
+static thread_local const char *t_failure_what = "";
+
+void note_launch_failure(hipError_t e, const char *what) {
+  if (t_failure == hipSuccess) {
+    t_failure = e;
+    t_failure_what = what;
+  }
+}
+
+hipError_t take_launch_failure(const char **what) {
+  const hipError_t e = t_failure;
+  if (what) *what = t_failure_what;
+  t_failure = hipSuccess;
+  t_failure_what = "";
+  return e;
+}
+
 int grid_for(int64_t items) {
   int64_t b = (items + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -1083,31 +1103,121 @@ __global__ __launch_bounds__(kBlock) void k_assemble(IeGeom g, IeBc bc, double d
 }
 
 // State update of ImplicitEuler::timestep, include/time_disc.hpp:281-286:
-// T += delta and max |delta| over interior cells only.
+// T += delta on interior cells, and the ingredients of the returned maximum.
+//
+// The reference folds `max_delta = std::max(std::abs(delta), max_delta)` over the
+// interior cells in (i, j) order (:284).  std::max(a, b) is `(a < b) ? b : a`, and
+// every comparison with a NaN is false: a NaN |delta| replaces the running maximum,
+// and the next finite |delta| replaces a NaN maximum.  The fold therefore returns
+// the maximum over the cells AFTER the last NaN cell, and NaN only when the last
+// interior cell is NaN.  Here every workgroup records the largest |delta| that is
+// not NaN (part[2 b]) and the largest position of a NaN (part[2 b + 1]; position =
+// index in the padded layout of the whole mesh, which grows in (i, j) order; -1 if
+// none); k_max_fold turns them into the reference's value.
+__device__ __forceinline__ double max_skip_nan(double a, double m) { return a > m ? a : m; }
+
 __global__ __launch_bounds__(kBlock) void k_update_max(IeGeom g, double *__restrict__ T,
                                                         const double *__restrict__ delta,
                                                         double *__restrict__ part) {
-  __shared__ double s[kBlock / 64];
+  __shared__ double s[2 * (kBlock / 64)];
   const int P = g.cy + 2;
   const int64_t nloc = (int64_t)g.rows * P;
-  double m = 0.0;
+  double m = 0.0, last_nan = -1.0;
   for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (int64_t)gridDim.x * kBlock) {
     const int ip = g.row0 + (int)(k / P), jp = (int)(k % P);
     if (ip >= 1 && ip <= g.cx && jp >= 1 && jp <= g.cy) {
       const double d = delta[k];
       T[k] = T[k] + d;
-      m = nan_max(fabs(d), m);
+      const double a = fabs(d);
+      m = max_skip_nan(a, m);
+      if (a != a) last_nan = (double)((int64_t)g.row0 * P + k);  // positions grow along a thread's walk
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = nan_max(m, __shfl_down(m, off, 64));
+  for (int off = 32; off > 0; off >>= 1) {
+    m = max_skip_nan(__shfl_down(m, off, 64), m);
+    last_nan = max_skip_nan(__shfl_down(last_nan, off, 64), last_nan);
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) s[wv] = m;
+  if (lane == 0) {
+    s[2 * wv] = m;
+    s[2 * wv + 1] = last_nan;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = s[0];
-    for (int i = 1; i < kBlock / 64; i++) t = nan_max(t, s[i]);
-    part[blockIdx.x] = t;
+    for (int i = 1; i < kBlock / 64; i++) {
+      m = max_skip_nan(s[2 * i], m);
+      last_nan = max_skip_nan(s[2 * i + 1], last_nan);
+    }
+    part[2 * blockIdx.x] = m;
+    part[2 * blockIdx.x + 1] = last_nan;
+  }
+}
+
+// The reference's fold from the partial results of k_update_max, in up to three
+// phases (bits of `phases`) so that a row-block decomposition can reduce over
+// the ranks in between; scal = {result, last NaN position, largest |delta| that is not NaN}.
+//   1: collapse the workgroups' partial results into scal[1], scal[2]
+//   2: scal[0] = scal[2] if no cell is NaN; otherwise the largest |delta| over this
+//      rank's interior cells behind the last NaN position (one workgroup walks them:
+//      only runs whose solve has broken down get here)
+//   4: scal[0] = NaN if the last interior cell of the mesh is the last NaN position
+constexpr int kFoldBlock = 1024;
+
+__device__ __forceinline__ double fold_block_max(double v, double *s) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max_skip_nan(__shfl_down(v, off, 64), v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  double t = s[0];
+  for (int i = 1; i < kFoldBlock / 64; i++) t = max_skip_nan(s[i], t);
+  return t;  // the same value in every thread
+}
+
+__global__ __launch_bounds__(kFoldBlock) void k_max_fold(IeGeom g, const double *__restrict__ delta,
+                                                          const double *__restrict__ part, int np,
+                                                          double *__restrict__ scal, int phases) {
+  __shared__ double s[kFoldBlock / 64];
+  const int P = g.cy + 2;
+  double last_nan, mx;
+  if (phases & 1) {
+    double m = 0.0, l = -1.0;
+    for (int i = threadIdx.x; i < np; i += kFoldBlock) {
+      m = max_skip_nan(part[2 * i], m);
+      l = max_skip_nan(part[2 * i + 1], l);
+    }
+    mx = fold_block_max(m, s);
+    last_nan = fold_block_max(l, s);
+    if (threadIdx.x == 0) {
+      scal[1] = last_nan;
+      scal[2] = mx;
+    }
+  } else {
+    last_nan = scal[1];
+    mx = scal[2];
+  }
+  double res = mx;
+  if (phases & 2) {
+    if (last_nan >= 0.0) {
+      const int64_t nloc = (int64_t)g.rows * P;
+      int64_t k0 = (int64_t)last_nan + 1 - (int64_t)g.row0 * P;
+      if (k0 < 0) k0 = 0;
+      double m = 0.0;
+      for (int64_t k = k0 + threadIdx.x; k < nloc; k += kFoldBlock) {
+        const int ip = g.row0 + (int)(k / P), jp = (int)(k % P);
+        if (ip >= 1 && ip <= g.cx && jp >= 1 && jp <= g.cy) m = max_skip_nan(fabs(delta[k]), m);
+      }
+      res = fold_block_max(m, s);
+    }
+    if (threadIdx.x == 0) scal[0] = res;
+  } else {
+    res = scal[0];
+  }
+  if ((phases & 4) && threadIdx.x == 0) {
+    const double last_cell = (double)((int64_t)g.cx * P + g.cy);
+    if (last_nan == last_cell) scal[0] = __builtin_nan("");
   }
 }
 
@@ -1184,7 +1294,9 @@ __global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt,
                                                     double *__restrict__ ud, double *__restrict__ part) {
   const int P = g.cy + 2;
   const int j = blockIdx.x * 64 + threadIdx.x;  // interior column
-  double m = 0.0;
+  // the step's maximum runs over the lines in the order j = 0 .. cy-1 and along each over
+  // the entries 0 .. cx-1: position j cx + ip (see k_update_max for the fold's semantics)
+  double m = 0.0, last_nan = -1.0;
   if (j < g.cy) {
     const int64_t col = j + 1;
     const double kx = g.diffusion * g.inv_rp / g.dx;
@@ -1221,21 +1333,43 @@ __global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt,
       const double x = y[k] - next * ud[k];
       next = x;
       if (ip >= 1) T[k] = T[k] + x;
-      if (ip <= g.cx - 1) m = nan_max(fabs(x), m);
+      if (ip <= g.cx - 1 && last_nan < 0.0) {
+        // walking backwards: the first NaN met is the line's last one, and the maximum stops there
+        const double a = fabs(x);
+        if (a != a) last_nan = (double)((int64_t)j * g.cx + ip);
+        else m = max_skip_nan(a, m);
+      }
     }
   }
+  // the workgroup's summary: its last NaN position, and its maximum behind that position
+  // (lanes of later lines have no NaN, or the position would be theirs)
+  double lb = last_nan;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = nan_max(m, __shfl_down(m, off, 64));
-  if (threadIdx.x == 0) part[blockIdx.x] = m;
+  for (int off = 32; off > 0; off >>= 1) lb = max_skip_nan(__shfl_xor(lb, off, 64), lb);
+  if (lb >= 0.0 && (int64_t)j < (int64_t)lb / g.cx) m = 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max_skip_nan(__shfl_down(m, off, 64), m);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = m;
+    part[2 * blockIdx.x + 1] = lb;
+  }
 }
 
-__global__ __launch_bounds__(64) void k_max_final(const double *__restrict__ part, int np,
-                                                   double *__restrict__ out) {
-  double m = 0.0;
-  for (int i = threadIdx.x; i < np; i += 64) m = nan_max(m, part[i]);
+// The fold of ImplicitEulerApproxFact::timestep (include/time_disc.hpp:478-479; same
+// std::max semantics as above) from the workgroups' summaries of k_af_sweep_x:
+// the maximum behind the last NaN position, NaN if that is the last position.
+__global__ __launch_bounds__(64) void k_af_max_final(IeGeom g, const double *__restrict__ part, int np,
+                                                      double *__restrict__ out) {
+  double l = -1.0;
+  for (int i = threadIdx.x; i < np; i += 64) l = max_skip_nan(part[2 * i + 1], l);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = nan_max(m, __shfl_down(m, off, 64));
-  if (threadIdx.x == 0) *out = m;
+  for (int off = 32; off > 0; off >>= 1) l = max_skip_nan(__shfl_xor(l, off, 64), l);
+  const int first = l < 0.0 ? 0 : (int)(((int64_t)l / g.cx) / 64);  // workgroup of the line that holds the position
+  double m = 0.0;
+  for (int i = first + threadIdx.x; i < np; i += 64) m = max_skip_nan(part[2 * i], m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max_skip_nan(__shfl_down(m, off, 64), m);
+  if (threadIdx.x == 0) *out = l == (double)((int64_t)g.cx * g.cy - 1) ? __builtin_nan("") : m;
 }
 
 // ---------------------------------------------------------------------------
@@ -1595,8 +1729,13 @@ void launch_af_sweep_x(hipStream_t st, const IeGeom &g, const IeBc &bc, double d
   hipLaunchKernelGGL(k_af_sweep_x, dim3(gr), dim3(64), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
 }
 
-void launch_max_final(hipStream_t st, const double *part, int nparts, double *out) {
-  hipLaunchKernelGGL(k_max_final, dim3(1), dim3(64), 0, st, part, nparts, out);
+void launch_max_fold(hipStream_t st, const IeGeom &g, const double *delta, const double *part, int nparts,
+                     double *scal, int phases) {
+  hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(kFoldBlock), 0, st, g, delta, part, nparts, scal, phases);
+}
+
+void launch_af_max_final(hipStream_t st, const IeGeom &g, const double *part, int nparts, double *out) {
+  hipLaunchKernelGGL(k_af_max_final, dim3(1), dim3(64), 0, st, g, part, nparts, out);
 }
 
 }  // namespace kry

@@ -341,6 +341,15 @@ class ImplicitEuler:
         check(capi.lib().kry_ie_timestep(self.h, dt, C.byref(d)))
         return d.value
 
+    def apply_delta(self, delta_local):
+        """T += delta on interior cells and the step's maximum for a given delta
+        (owned rows, padded layout): the tail of ImplicitEuler::timestep."""
+        a = np.ascontiguousarray(delta_local, dtype=np.float64).reshape(-1)
+        assert a.shape[0] == self.nloc
+        d = C.c_double()
+        check(capi.lib().kry_ie_apply_delta(self.h, a.ctypes.data_as(_dp), C.byref(d)))
+        return d.value
+
     def timestep_async(self, dt):
         self._push_bc_values(self.cur_time())
         check(capi.lib().kry_ie_timestep_async(self.h, dt))

@@ -672,16 +672,65 @@ ORC_API double orc_flux_integral(const orc_ie *s, int i, int j) {
   return (-x_deriv - y_deriv) + s->diffusion * lapl_T_flux_integral(s, i, j);
 }
 
-/* SecondOrderCentered::source_fd and the four centred differences,
- * include/space_disc.hpp:145-179 */
+/* The four centred differences, include/space_disc.hpp:157-179 */
+static double du_dx_fd(const orc_ie *s, int i, int j) {
+  return (AT(s, 1, i + 1, j) - AT(s, 1, i - 1, j)) / (2.0 * s->dx);
+}
+static double du_dy_fd(const orc_ie *s, int i, int j) {
+  return (AT(s, 1, i, j + 1) - AT(s, 1, i, j - 1)) / (2.0 * s->dy);
+}
+static double dv_dx_fd(const orc_ie *s, int i, int j) {
+  return (AT(s, 2, i + 1, j) - AT(s, 2, i - 1, j)) / (2.0 * s->dx);
+}
+static double dv_dy_fd(const orc_ie *s, int i, int j) {
+  return (AT(s, 2, i, j + 1) - AT(s, 2, i, j - 1)) / (2.0 * s->dy);
+}
+
+/* SecondOrderCentered::source_fd, include/space_disc.hpp:145-155 */
 ORC_API double orc_source_fd(const orc_ie *s, int i, int j) {
-  const double u_dx = (AT(s, 1, i + 1, j) - AT(s, 1, i - 1, j)) / (2.0 * s->dx);
-  const double v_dy = (AT(s, 2, i, j + 1) - AT(s, 2, i, j - 1)) / (2.0 * s->dy);
-  const double u_dy = (AT(s, 1, i, j + 1) - AT(s, 1, i, j - 1)) / (2.0 * s->dy);
-  const double v_dx = (AT(s, 2, i + 1, j) - AT(s, 2, i - 1, j)) / (2.0 * s->dx);
+  const double u_dx = du_dx_fd(s, i, j);
+  const double v_dy = dv_dy_fd(s, i, j);
+  const double u_dy = du_dy_fd(s, i, j);
+  const double v_dx = dv_dx_fd(s, i, j);
   const double cross_term = u_dy + v_dx;
   return s->eckert / s->reynolds *
          (2.0 * (u_dx * u_dx + v_dy * v_dy) + cross_term * cross_term);
+}
+
+/* One member function of SecondOrderCentered / EnergyAssembly evaluated on every
+ * interior cell (i, j), i slow: the loops of the reference's own tests
+ * (src/test.cpp:753-763, :798-820, :845-888, ...).  out holds cx * cy values. */
+enum {
+  ORC_Q_DX_M1 = 0, ORC_Q_DX_0, ORC_Q_DX_P1, ORC_Q_DY_M1, ORC_Q_DY_0, ORC_Q_DY_P1,
+  ORC_Q_DX_FLUX, ORC_Q_DY_FLUX, ORC_Q_LAPL_T_FLUX_INTEGRAL, ORC_Q_FLUX_INTEGRAL,
+  ORC_Q_DU_DX_FD, ORC_Q_DV_DY_FD, ORC_Q_DU_DY_FD, ORC_Q_DV_DX_FD, ORC_Q_SOURCE_FD
+};
+ORC_API int orc_eval_cells(const orc_ie *s, int what, double *out) {
+  for (int i = 0; i < s->cx; i++) {
+    for (int j = 0; j < s->cy; j++) {
+      double v;
+      switch (what) {
+        case ORC_Q_DX_M1: v = Dx_m1(s, i, j); break;
+        case ORC_Q_DX_0: v = Dx_0(s); break;
+        case ORC_Q_DX_P1: v = Dx_p1(s, i, j); break;
+        case ORC_Q_DY_M1: v = Dy_m1(s, i, j); break;
+        case ORC_Q_DY_0: v = Dy_0(s); break;
+        case ORC_Q_DY_P1: v = Dy_p1(s, i, j); break;
+        case ORC_Q_DX_FLUX: v = dx_flux(s, i, j); break;
+        case ORC_Q_DY_FLUX: v = dy_flux(s, i, j); break;
+        case ORC_Q_LAPL_T_FLUX_INTEGRAL: v = lapl_T_flux_integral(s, i, j); break;
+        case ORC_Q_FLUX_INTEGRAL: v = orc_flux_integral(s, i, j); break;
+        case ORC_Q_DU_DX_FD: v = du_dx_fd(s, i, j); break;
+        case ORC_Q_DV_DY_FD: v = dv_dy_fd(s, i, j); break;
+        case ORC_Q_DU_DY_FD: v = du_dy_fd(s, i, j); break;
+        case ORC_Q_DV_DX_FD: v = dv_dx_fd(s, i, j); break;
+        case ORC_Q_SOURCE_FD: v = orc_source_fd(s, i, j); break;
+        default: return 1;
+      }
+      out[(size_t)i * s->cy + j] = v;
+    }
+  }
+  return 0;
 }
 
 /* BoundaryCondition::ghost_cell, include/boundary_conds.hpp:62-66 */

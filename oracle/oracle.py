@@ -109,6 +109,7 @@ def lib():
     sig("orc_flux_integral", C.c_double, _vp, C.c_int, C.c_int)
     sig("orc_source_fd", C.c_double, _vp, C.c_int, C.c_int)
     sig("orc_ghost_cell", C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
+    sig("orc_eval_cells", C.c_int, _vp, C.c_int, _dp)
     for nm in ("orc_left_x", "orc_right_x", "orc_bottom_y", "orc_top_y",
                "orc_median_x", "orc_median_y"):
         sig(nm, C.c_double, _vp, C.c_int)
@@ -444,6 +445,18 @@ class ImplicitEuler:
 
     def op(self):
         return Op(lib().orc_ie_op(self.h), self.n, None)
+
+    # member functions of SecondOrderCentered / EnergyAssembly (include/space_disc.hpp)
+    QUANTITIES = ("Dx_m1", "Dx_0", "Dx_p1", "Dy_m1", "Dy_0", "Dy_p1", "dx_flux", "dy_flux",
+                  "lapl_T_flux_integral", "flux_integral", "du_dx_fd", "dv_dy_fd", "du_dy_fd", "dv_dx_fd",
+                  "source_fd")
+
+    def eval_cells(self, name):
+        """One of QUANTITIES on every interior cell: array (cx, cy)."""
+        out = np.empty((self.cx, self.cy))
+        rc = lib().orc_eval_cells(self.h, self.QUANTITIES.index(name), out.ctypes.data_as(_dp))
+        assert rc == 0
+        return out
 
     def flux_integral(self, i, j):
         return lib().orc_flux_integral(self.h, i, j)

@@ -145,3 +145,48 @@ def test_timesteps_match_cpu_statement(ctx, oracle, name, args, m, tdp):
     T = dev.field(capi.FIELD_T)[1:-1, 1:-1]
     Tr = ref.field(0)[1:-1, 1:-1]
     assert rel(T, Tr) <= 1e-10
+
+
+def test_early_convergence_after_a_later_hand_over(ctx, oracle):
+    """A solve that meets its tolerance within the chain steps never runs the
+    one-sweep steps: the scale factors those steps keep per basis slot must not
+    survive from an earlier solve (they start every cycle at 1).  First a long
+    solve with the default hand-over (slots 3.. get scale factors != 1), then
+    the hand-over moves to step 12 and a loose tolerance is met after seven
+    chain steps."""
+    prob = problems.s_iso(64, 48)
+    m = 20
+    ref = oracle.ImplicitEuler(**prob, m=m)
+    ref.assemble_system(0.25)
+    b = ref.sol_vec()
+    dev = host.ImplicitEuler(ctx, **prob, m=m, extended=(1e-12, 10))
+    dev.assemble_system(0.25)
+    g = dev.solver()
+    x = dev.compact(g.solve(dev.operator(), dev.expand(b).reshape(-1)))
+    assert g.last_stats()[0] > 12
+    g.set_one_sweep(12)
+    assert g.get_one_sweep() == 12
+    g.set_tolerance(5e-2, 10)
+    gref = oracle.Gmres(ref.n, m)
+    gref.set_extended(5e-2, 10)
+    x_ref = gref.solve(ref.op(), b)
+    x = dev.compact(g.solve(dev.operator(), dev.expand(b).reshape(-1)))
+    it, cy, cv, rr = g.last_stats()
+    assert cv and it == gref.last_stats()[0] and it < 12
+    assert rel(x, x_ref) <= 1e-10
+
+
+def test_hand_over_stays_within_the_chains_first_group(ctx, oracle):
+    """The first one-sweep step needs the Gram matrix of every stored vector;
+    the chain carries Gram entries only within a group of `mgs_block` vectors,
+    so the hand-over step in effect is at most mgs_block - 1."""
+    prob = problems.s_iso(40, 30)
+    m = 20
+    ref = oracle.ImplicitEuler(**prob, m=m)
+    ref.assemble_system(0.25)
+    x_ref = ref.solver().solve(ref.op(), ref.sol_vec())
+    dev = host.ImplicitEuler(ctx, **prob, m=m, mgs_block=4, one_sweep=9)
+    assert dev.solver().get_one_sweep() == 3
+    dev.assemble_system(0.25)
+    x = dev.compact(dev.solver().solve(dev.operator(), dev.expand(ref.sol_vec())))
+    assert rel(x, x_ref) <= 1e-12

@@ -590,15 +590,47 @@ def test_prob1_replay_to_steady_state(ctx, oracle, graph):
     assert np.isnan(T[0, 0]) and np.isnan(T[-1, -1])
 
 
-def test_preconditioned_divergence_reaches_nan(ctx):
+def test_graph_replay_follows_configuration_changes(ctx):
+    """A captured step is recorded again after a setter changed which kernels
+    a solve launches: with the one-sweep steps switched off between two
+    replays, the second replay must be the chain's result (bit for bit the
+    eager chain's), not a replay of the kernels captured before."""
+    def run(graph, switch):
+        dev = host.ImplicitEuler(ctx, **problems.s_iso(96, 64), m=12, use_graph=graph, bc_time_dependent=False)
+        d = [dev.timestep(0.25)]
+        if switch:
+            dev.solver().set_one_sweep(-1)
+            dev.solver().set_mgs_block(4)
+        d.append(dev.timestep(0.25))
+        return d, dev.field(0), dev.solver().hessenberg_matrix()
+    for switch in (False, True):
+        (d0, T0, H0), (d1, T1, H1) = run(False, switch), run(True, switch)
+        assert d0 == d1 and np.array_equal(T0, T1, equal_nan=True) and np.array_equal(H0, H1)
+    assert not np.array_equal(run(True, False)[2], run(True, True)[2])
+
+
+def test_preconditioned_divergence_reaches_nan(ctx, oracle):
     """The default solver of scripts/prob1.py diverges; the step keeps
-    returning finite growth and finally NaN, which ends prob1's loop."""
+    returning finite growth and finally NaN, which ends prob1's loop
+    (`while max_delta > 1e-9`), at the same step as the reference.  While the
+    solution overflows, some cells are NaN and others are not: the returned
+    value follows the reference's std::max fold (the maximum behind the last
+    NaN cell, include/time_disc.hpp:284), so the sequence of NaN / non-NaN
+    results equals the CPU restatement's step by step."""
     dev = host.ImplicitEuler(ctx, **problems.prob1(), m=10, tdp=True)
+    ref = oracle.ImplicitEuler(**problems.prob1(), m=10, tdp=True)
     run = _golden()["runs"][0]
     seq = [dev.timestep(0.25) for _ in range(90)]
+    seq_ref = [ref.timestep(0.25) for _ in range(90)]
     assert abs(seq[50] - run["max_delta"]["50"]) <= 1e-6 * run["max_delta"]["50"]
     first_nan = next(i for i, v in enumerate(seq) if math.isnan(v)) + 1
-    assert abs(first_nan - run["first_nan_step_1based"]) <= 1
+    assert first_nan == run["first_nan_step_1based"]
+    assert [math.isnan(v) for v in seq] == [math.isnan(v) for v in seq_ref]
+    for k, (a, b) in enumerate(zip(seq, seq_ref)):
+        if math.isfinite(b):
+            assert abs(a - b) <= 1e-6 * abs(b), (k, a, b)
+        elif math.isinf(b):
+            assert a == b, (k, a, b)
 
 
 @pytest.mark.parametrize("name,make,shape,m,tdp", [
