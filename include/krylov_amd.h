@@ -297,6 +297,21 @@ int kry_ie_timestep(kry_ie *ie, double dt, double *max_delta);
  * previous result.  Time does not advance.  Collective on a row-block
  * decomposition. */
 int kry_ie_apply_delta(kry_ie *ie, const double *delta_local, double *max_delta);
+/* No counterpart in the reference.  The same state update for callers that
+ * cannot allocate device memory (code under hipGraph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no step object, nothing is allocated
+ * or freed, nothing waits for the device.  T_dev and delta_dev are
+ * (cx+2) x (cy+2) device arrays in padded layout (whole mesh), *max_delta_dev
+ * receives the maximum on the device; the work is queued on the context's
+ * stream.  The kernels' partial results live in a scratch array of 32.8 KB
+ * that is part of the library's device image (every GPU the library runs on
+ * holds one copy for the life of the process): calls that overlap on one GPU
+ * race on it, so keep them on one stream or order them yourself.  Meshes
+ * with more than KRY_NOALLOC_MAX_PADDED_CELLS padded cells are rejected
+ * (KRY_ERR_INVALID). */
+#define KRY_NOALLOC_MAX_PADDED_CELLS 2147483000LL
+int kry_apply_delta_noalloc(kry_ctx *ctx, int cx, int cy, double *T_dev, const double *delta_dev,
+                            double *max_delta_dev);
 /* The same step queued without reading max|delta| back (for back-to-back
  * steps with time-independent boundary values); fetch with kry_ie_last_max_delta. */
 int kry_ie_timestep_async(kry_ie *ie, double dt);

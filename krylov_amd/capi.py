@@ -88,6 +88,7 @@ SIGNATURES = {
     "kry_ie_assemble_system": (C.c_int, [_vp, C.c_double]),
     "kry_ie_timestep": (C.c_int, [_vp, C.c_double, _dp]),
     "kry_ie_apply_delta": (C.c_int, [_vp, _dp, _dp]),
+    "kry_apply_delta_noalloc": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "kry_ie_timestep_async": (C.c_int, [_vp, C.c_double]),
     "kry_ie_last_max_delta": (C.c_int, [_vp, _dp]),
     "kry_ie_timestep_approx_fact": (C.c_int, [_vp, C.c_double, _dp]),

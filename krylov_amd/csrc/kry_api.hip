@@ -56,6 +56,32 @@ static int fail(int code, const char *fmt, ...) {
 
 static const double kSNaN = std::numeric_limits<double>::signaling_NaN();
 
+// Scratch of kry_apply_delta_noalloc, an entry point for callers that cannot allocate
+// device memory: the per-workgroup partial results of the state update (2 * kMaxParts
+// doubles) followed by the three scalars of the fold (k_max_fold).  Every GPU the library
+// runs on holds its own copy of this array at its own address until the process ends.
+// In host code the name below is only a handle for hipGetSymbolAddress; the address the
+// kernels get is looked up once per device in kry_ctx_create (scratch_of_device).
+constexpr int kNoAllocScratchDoubles = 2 * kMaxParts + 4;
+static __device__ __align__(256) double scratch[kNoAllocScratchDoubles];
+constexpr int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices];  // device address of `scratch` per device id
+static std::mutex g_scratch_mutex;
+
+// Address of this device's copy of `scratch`; `device` must be the current device.
+static int scratch_of_device(int device, double **out) {
+  if (device < 0 || device >= kMaxDevices) return KRY_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    double *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return KRY_ERR_HIP;
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return KRY_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Handles
 // ---------------------------------------------------------------------------
@@ -83,6 +109,8 @@ struct kry_ctx {
   void *comm_user = nullptr;
   // ... or the library talks to RCCL itself on `stream` (kry_ctx_set_comm_rccl)
   ncclComm_t nccl = nullptr;
+  // this device's copy of the file-scope scratch array (kry_apply_delta_noalloc)
+  double *scratch = nullptr;
 };
 
 // RCCL entry points, resolved at run time so that single-GPU users never load
@@ -293,6 +321,10 @@ int kry_ctx_create(int device, void *stream, kry_ctx **out) {
   HIPCHK(hipSetDevice(device));
   kry_ctx *ctx = new kry_ctx;
   ctx->device = device;
+  if (device < kMaxDevices && scratch_of_device(device, &ctx->scratch) != KRY_OK) {
+    delete ctx;
+    return fail(KRY_ERR_HIP, "hipGetSymbolAddress of the library's scratch array failed on device %d", device);
+  }
   if (stream) {
     ctx->stream = (hipStream_t)stream;
   } else {
@@ -1771,6 +1803,34 @@ int kry_ie_apply_delta(kry_ie *ie, const double *delta_local, double *max_delta)
   KCHK(ie_update_async(ie));
   HIPCHK(hipStreamSynchronize(ie->ctx->stream));
   if (max_delta) *max_delta = *ie->maxd_h;
+  return KRY_OK;
+}
+
+// The state update for callers that cannot allocate: no step object (whose creation
+// allocates), device pointers in and out, partial results in the library's file-scope
+// scratch array.  Queues three things on the context's stream and returns.
+int kry_apply_delta_noalloc(kry_ctx *ctx, int cx, int cy, double *T_dev, const double *delta_dev,
+                            double *max_delta_dev) {
+  if (!ctx || !T_dev || !delta_dev || !max_delta_dev) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (cx < 1 || cy < 1) return fail(KRY_ERR_INVALID, "cells_x and cells_y must be positive");
+  if ((int64_t)(cx + 2) * (cy + 2) > KRY_NOALLOC_MAX_PADDED_CELLS)
+    return fail(KRY_ERR_INVALID, "a %d x %d mesh has more than %lld padded cells, the limit of kry_apply_delta_noalloc", cx, cy,
+                (long long)KRY_NOALLOC_MAX_PADDED_CELLS);
+  if (!ctx->scratch) return fail(KRY_ERR_STATE, "no scratch array on device %d (device ids up to %d are served)", ctx->device, kMaxDevices - 1);
+  HIPCHK(hipSetDevice(ctx->device));
+  IeGeom g{};
+  g.cx = cx;
+  g.cy = cy;
+  g.row0 = 0;
+  g.rows = cx + 2;
+  double *part = ctx->scratch, *scal = ctx->scratch + 2 * kMaxParts;
+  int np = 0;
+  // every partial result and scalar the fold reads is written by this call's kernels
+  // first: nothing in the scratch array has to start at zero
+  launch_update_max(ctx->stream, g, T_dev, delta_dev, part, &np);
+  launch_max_fold(ctx->stream, g, delta_dev, part, np, scal, 7);
+  KCHK(launch_ok("kry_apply_delta_noalloc"));
+  HIPCHK(hipMemcpyAsync(max_delta_dev, scal, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return KRY_OK;
 }
 
