@@ -166,6 +166,14 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host);
 int kry_gmres_hessenberg(kry_gmres *g, int i, int j, double *out);
 /* Whole (m+1) x m row-major Hessenberg array. */
 int kry_gmres_hessenberg_matrix(kry_gmres *g, double *out_host);
+/* The reduced least-squares solve of GMRESSolver::solve on its own
+ * (include/solver.hpp:142-151: sys = H^T H, rhs_i = beta H(0,i), then
+ * LUSolver::solve, :34-96, un-pivoted Doolittle LU) for a caller-supplied
+ * (num_iters+1) x num_iters row-major Hessenberg array: y_host receives the
+ * num_iters coefficients.  Every entry is produced by the reference's sequence
+ * of operations, so the result equals the reference's bit for bit.  Replaces the
+ * solver's Hessenberg matrix and beta. */
+int kry_gmres_reduced_solve(kry_gmres *g, const double *H_host, double beta, double *y_host);
 /* Solver::prev_result, include/solver.hpp:21 (signalling NaN before a solve). */
 int kry_gmres_prev_result(kry_gmres *g, double *out_host);
 /* Device pointer to the n-entry result vector. */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "kry_gmres_subspace_vector": (C.c_int, [_vp, C.c_int, _dp]),
     "kry_gmres_hessenberg": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "kry_gmres_hessenberg_matrix": (C.c_int, [_vp, _dp]),
+    "kry_gmres_reduced_solve": (C.c_int, [_vp, _dp, C.c_double, _dp]),
     "kry_gmres_prev_result": (C.c_int, [_vp, _dp]),
     "kry_gmres_result_device": (_vp, [_vp]),
     "kry_gmres_apply_preconditioner": (C.c_int, [_vp, _dp, _dp]),

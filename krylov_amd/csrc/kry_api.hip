@@ -233,7 +233,7 @@ struct kry_gmres {
   double *parts = nullptr;  // 2 x kMaxRed x kMaxParts (ping-pong partial sums)
   double *beta = nullptr;   // 1
   double *y = nullptr;      // m
-  double *work = nullptr;   // 3 m^2 + 2 m
+  double *work = nullptr;   // 3 m^2 + 3 m
   double *bbuf = nullptr;   // staging of a host right-hand side
   // tridiagonal preconditioner
   double *lo = nullptr, *di = nullptr, *up = nullptr;  // owned only for CSR operators
@@ -513,6 +513,37 @@ static int comm_halo(kry_ctx *ctx, double *local, int64_t P, int64_t nloc) {
   return KRY_OK;
 }
 
+// The same exchange for several slab vectors of one shape at once (the three mesh fields
+// after a ghost fill): through RCCL all their transfers form ONE group, i.e. one launch on
+// the stream instead of one per vector.
+static int comm_halo_multi(kry_ctx *ctx, double *const *locals, int count, int64_t P, int64_t nloc) {
+  if (ctx->nranks == 1) return KRY_OK;
+  if (!ctx->nccl) {
+    for (int f = 0; f < count; f++) KCHK(comm_halo(ctx, locals[f], P, nloc));
+    return KRY_OK;
+  }
+  const int down = ctx->rank > 0 ? ctx->rank - 1 : -1;
+  const int up = ctx->rank + 1 < ctx->nranks ? ctx->rank + 1 : -1;
+  const RcclApi &api = rccl_api();
+  NCCLCHK(api.GroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (int f = 0; f < count; f++) {
+    double *local = locals[f];
+    if (down >= 0) {
+      if (r == ncclSuccess) r = api.Send(local, (size_t)P, ncclDouble, down, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.Recv(local - P, (size_t)P, ncclDouble, down, ctx->nccl, ctx->stream);
+    }
+    if (up >= 0) {
+      if (r == ncclSuccess) r = api.Send(local + nloc - P, (size_t)P, ncclDouble, up, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.Recv(local + nloc, (size_t)P, ncclDouble, up, ctx->nccl, ctx->stream);
+    }
+  }
+  const ncclResult_t e = api.GroupEnd();
+  if (r != ncclSuccess) return fail(KRY_ERR_HIP, "ncclSend/ncclRecv: %s", api.GetErrorString(r));
+  if (e != ncclSuccess) return fail(KRY_ERR_HIP, "ncclGroupEnd: %s", api.GetErrorString(e));
+  return KRY_OK;
+}
+
 // One send and one receive of `count` doubles (a peer < 0: no such transfer).
 static int comm_sendrecv(kry_ctx *ctx, const double *send, int send_peer, double *recv, int recv_peer, int64_t count) {
   if (ctx->nccl) {
@@ -776,7 +807,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   if (st == KRY_OK) st = dev_alloc(&g->G, (int64_t)(m + 1) * (m + 1));
   if (st == KRY_OK) st = dev_alloc(&g->beta, 1);
   if (st == KRY_OK) st = dev_alloc(&g->y, m);
-  if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 2 * m);
+  if (st == KRY_OK) st = dev_alloc(&g->work, 3 * (int64_t)m * m + 3 * m);
   if (st == KRY_OK && (flags & KRY_GMRES_EXTENDED)) {
     st = dev_alloc(&g->R, (int64_t)(m + 1) * m + 3 * (int64_t)m + 1);
     if (st == KRY_OK && hipMalloc((void **)&g->ext, sizeof(ExtState)) != hipSuccess)
@@ -979,9 +1010,11 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   }
   g->nvec = 1;
   g->scaled = false;
-  // every vector starts a cycle normalised; the one-sweep steps overwrite the entries of
-  // the slots they fill (never predicated: a monitored solve may stop before they run)
-  if (g->fsigma) launch_fill(st, g->fsigma, 1.0, kFusedCoef);
+  // Every vector starts a cycle normalised; the one-sweep steps overwrite the scale factors
+  // of the slots they fill.  A monitored solve may stop before they run (their kernels,
+  // the hand-over included, are predicated), so there the factors are reset here; a fixed
+  // cycle always runs the hand-over, which resets them itself.
+  if (g->fsigma && (g->flags & KRY_GMRES_EXTENDED)) launch_fill(st, g->fsigma, 1.0, kFusedCoef);
   return launch_ok("initial_subspace");
 }
 
@@ -1359,6 +1392,20 @@ int kry_gmres_hessenberg_matrix(kry_gmres *g, double *out_host) {
   return KRY_OK;
 }
 
+int kry_gmres_reduced_solve(kry_gmres *g, const double *H_host, double beta, double *y_host) {
+  if (!g || !H_host || !y_host) return fail(KRY_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  hipStream_t st = g->ctx->stream;
+  const int m = g->m;
+  HIPCHK(hipMemcpyAsync(g->H, H_host, sizeof(double) * (size_t)(m + 1) * m, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(g->beta, &beta, sizeof(double), hipMemcpyHostToDevice, st));
+  launch_small_solve(st, g->H, g->beta, m, g->y, g->work);
+  KCHK(launch_ok("kry_gmres_reduced_solve"));
+  HIPCHK(hipMemcpyAsync(y_host, g->y, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return KRY_OK;
+}
+
 int kry_gmres_prev_result(kry_gmres *g, double *out_host) {
   if (!g || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(g->ctx->device));
@@ -1597,7 +1644,7 @@ static int ie_apply_bcs_async(kry_ie *ie, bool force_upload) {
   launch_pack_wrap(st, ie->g, ie->fld[0], ie->fld[1], ie->fld[2], ie->wrap);
   KCHK(comm_allreduce(ie->ctx, ie->wrap, 3 * (int64_t)ie->g.cy, KRY_REDUCE_SUM));
   launch_bc_fill(st, ie->g, ie->bc, ie->fld[0], ie->fld[1], ie->fld[2], ie->bcvals, ie->wrap);
-  for (int f = 0; f < 3; f++) KCHK(comm_halo(ie->ctx, ie->fld[f], ie->g.cy + 2, ie->nloc));
+  KCHK(comm_halo_multi(ie->ctx, ie->fld, 3, ie->g.cy + 2, ie->nloc));
   return KRY_OK;
 }
 

@@ -100,6 +100,53 @@ __device__ __forceinline__ double opaque(double x) {
 // The diagonal entry all interior cells share.
 __device__ __forceinline__ double gdiag_of(const BandGen &gen) { return *gen.cdiag; }
 
+// Coefficients of step i from the totals of the sweep that produced s_i and
+// t_i = A s_i (layout of k_arnoldi_fused<i-1>), or, with boot, from the totals
+// of the operator kernel applied to the normalised v_i (i + 1 dots, then the i
+// Gram entries of v_i; sigma_0..sigma_i := 1).  Stores sigma_i = ||s_i||, column i
+// of G and of H, H[i][i-1] = sigma_i, coef[k] = h_k / sigma_k (k <= i) and
+// coef[kFusedNormSlot] = sigma_i.  Called by every thread of a workgroup; the first
+// wavefront does the recurrence.  gs: i (i + 1) doubles of LDS.
+__device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int boot, double *G, int gld, double *H,
+                                                  int m, double *coef, double *sigma, double *gs) {
+  const int lane = threadIdx.x;  // only lanes of the first wavefront own a vector
+  const int gp = i + 1;          // row pitch of gs
+  const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
+  const double sk = (boot || lane >= i) ? (lane == i ? nrm : 1.0) : sigma[lane];  // sigma of "my" vector
+  // earlier Gram columns
+  for (int e = threadIdx.x; e < i * i; e += blockDim.x) {
+    const int a = e / i, k = e % i;
+    gs[a * gp + k] = a < k ? G[(size_t)a * gld + k] : 0.0;
+  }
+  if (lane < i) {
+    const double g = boot ? tot[i + 1 + lane] : tot[i + 1 + lane] / sk / nrm;
+    gs[lane * gp + i] = g;
+    G[(size_t)lane * gld + i] = g;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  double v = 0.0;
+  if (lane <= i) {
+    if (boot)
+      v = tot[lane];
+    else
+      v = tot[lane] / sk / nrm;  // lane == i: <t, s_i> / sigma_i^2
+  }
+  for (int a = 0; a < i; a++) {
+    const double ha = __shfl(v, a, 64);
+    if (lane > a && lane <= i) v = v - ha * gs[a * gp + lane];
+  }
+  if (lane <= i) {
+    coef[lane] = v / sk;
+    H[(size_t)lane * m + i] = v;
+    if (boot || lane == i) sigma[lane] = sk;
+  }
+  if (lane == 0) {
+    coef[kFusedNormSlot] = nrm;
+    if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
+  }
+}
+
 // NV: step number; s_0..s_{NV-1} are read from V, s_NV from u_in (it is slot NV of the
 // same array; a separate argument keeps the register arrays NV long).
 // u: the new vector s_{NV+1}.  t_NV = A s_NV is not stored by the previous sweep but
@@ -705,12 +752,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts_wide(const double *__re
   if (threadIdx.x == 0) tot[q] = r;
 }
 
-// Coefficients of step i from the totals of the sweep that produced s_i and
-// t_i = A s_i (layout of k_arnoldi_fused<i-1>), or, with boot, from the totals
-// of the operator kernel applied to the normalised v_i (i + 1 dots, then the i
-// Gram entries of v_i; sigma_0..sigma_i := 1).  Stores sigma_i = ||s_i||, column i
-// of G and of H, H[i][i-1] = sigma_i, coef[k] = h_k / sigma_k (k <= i) and
-// coef[kFusedNormSlot] = sigma_i.
+// The coefficients of step i as a kernel of its own (see fused_coeffs_body): the hand-over
+// from the chain (boot), and every step on several ranks, where the totals are all-reduced.
 __global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ tot, int i, int boot,
                                                       double *__restrict__ G, int gld,
                                                       double *__restrict__ H, int m,
@@ -718,41 +761,8 @@ __global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ 
                                                       double *__restrict__ sigma,
                                                       const int *__restrict__ stop) {
   if (stopped(stop)) return;
-  __shared__ double gs[kFusedMaxM * kFusedMaxM];
-  const int lane = threadIdx.x;
-  const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
-  const double sk = (boot || lane >= i) ? (lane == i ? nrm : 1.0) : sigma[lane];  // sigma of "my" vector
-  // earlier Gram columns
-  for (int e = lane; e < i * i; e += 64) {
-    const int a = e / i, k = e % i;
-    gs[a * kFusedMaxM + k] = a < k ? G[(size_t)a * gld + k] : 0.0;
-  }
-  if (lane < i) {
-    const double g = boot ? tot[i + 1 + lane] : tot[i + 1 + lane] / sk / nrm;
-    gs[lane * kFusedMaxM + i] = g;
-    G[(size_t)lane * gld + i] = g;
-  }
-  __syncthreads();
-  double v = 0.0;
-  if (lane <= i) {
-    if (boot)
-      v = tot[lane];
-    else
-      v = tot[lane] / sk / nrm;  // lane == i: <t, s_i> / sigma_i^2
-  }
-  for (int a = 0; a < i; a++) {
-    const double ha = __shfl(v, a, 64);
-    if (lane > a && lane <= i) v = v - ha * gs[a * kFusedMaxM + lane];
-  }
-  if (lane <= i) {
-    coef[lane] = v / sk;
-    H[(size_t)lane * m + i] = v;
-    if (boot || lane == i) sigma[lane] = sk;
-  }
-  if (lane == 0) {
-    coef[kFusedNormSlot] = nrm;
-    if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
-  }
+  __shared__ double gs[kFusedMaxM * (kFusedMaxM + 1)];
+  fused_coeffs_body(tot, i, boot, G, gld, H, m, coef, sigma, gs);
 }
 
 // End of a cycle: sigma_m = ||s_m|| from the closing kernel's total, H[m][m-1] = sigma_m.
@@ -784,23 +794,6 @@ int split_from() {
     g_split_from.store(v, std::memory_order_relaxed);
   }
   return v < 12 ? 12 : v;
-}
-
-// A sweep that needs more than 64 KB of LDS has to be allowed to, once per kernel and
-// DEVICE (a process may hold contexts on several).  `done` has one bit per device id.
-template <typename K>
-void allow_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done, const char *what) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;  // beyond 63: set it every time
-  const uint64_t bit = 1ull << dev;
-  if (dev < 63 && (done.load(std::memory_order_acquire) & bit)) return;
-  const hipError_t e =
-      hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) {
-    note_launch_failure(e, what);
-    return;
-  }
-  done.fetch_or(bit, std::memory_order_release);
 }
 
 // Strips and bands for step nv.  A band of R rows costs about kBandOverhead rows more than

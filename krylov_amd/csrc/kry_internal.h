@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "krylov_amd.h"
 
 namespace kry {
@@ -75,6 +77,23 @@ class LaunchPredicate {
 // and the entry point that queued the work reports it (take: returns it and clears it).
 void note_launch_failure(hipError_t e, const char *what);
 hipError_t take_launch_failure(const char **what);
+
+// A kernel that needs more than 64 KB of LDS has to be allowed to, once per kernel and
+// DEVICE (a process may hold contexts on several).  `done` has one bit per device id.
+template <typename K>
+inline void allow_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done, const char *what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;  // beyond 63: set it every time
+  const uint64_t bit = 1ull << dev;
+  if (dev < 63 && (done.load(std::memory_order_acquire) & bit)) return;
+  const hipError_t e =
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    note_launch_failure(e, what);
+    return;
+  }
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 // ---- launchers (all asynchronous on `st`) ---------------------------------
 int grid_for(int64_t items);

@@ -588,18 +588,36 @@ __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__
 // Reduced (m x m) least-squares solve, include/solver.hpp:142-151 with
 // LUSolver::lu_decomp (:58-96) and LUSolver::solve (:34-56).  One workgroup;
 // every matrix entry is produced by exactly the reference's sequence of
-// multiplies, subtracts and divides, entries of one elimination step are
-// spread over the lanes.
+// multiplies, subtracts and divides; only independent entries are spread over
+// the lanes:
+//   * the entries of H^T H, and of row k of u / column k of l in elimination step k
+//     (each a chain over the earlier steps in ascending order, as in the reference);
+//   * the forward substitution, column by column: once partial(j) is final, every
+//     later row subtracts l(i,j) partial(j) -- rows receive their terms in ascending
+//     j, the order of :42-44;
+//   * the back substitution stays one sequential walk: row i subtracts its terms in
+//     ASCENDING j (:50-52) and the first of them, u(i,i+1) vars(i+1), is the last
+//     value to become known.
+// With LDS the three m x m arrays live in LDS (60 KB for m = 50; up to kSmallLdsMaxM),
+// otherwise in `work` (3 m^2 + 3 m doubles of global memory).  l is kept transposed
+// (lt[i m + j] = l(j,i)): the lanes that own different rows j then read neighbouring
+// addresses.
 // ---------------------------------------------------------------------------
+constexpr int kSmallLdsMaxM = 64;
+
+template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_small_solve(const double *__restrict__ H,
                                                          const double *__restrict__ beta_p, int m,
                                                          double *__restrict__ y,
                                                          double *__restrict__ work) {
-  double *sys = work;
-  double *l = work + (size_t)m * m;
-  double *u = work + 2 * (size_t)m * m;
-  double *rhs = work + 3 * (size_t)m * m;
+  extern __shared__ double small_lds[];
+  double *base = LDS ? small_lds : work;
+  double *sys = base;
+  double *lt = base + (size_t)m * m;
+  double *u = base + 2 * (size_t)m * m;
+  double *rhs = base + 3 * (size_t)m * m;
   double *partial = rhs + m;
+  double *ys = partial + m;
   const int tid = threadIdx.x;
   const double beta = *beta_p;
   for (int e = tid; e < m * m; e += kBlock) {
@@ -607,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void k_small_solve(const double *__restrict
     double acc = 0.0;
     for (int k = 0; k < m + 1; k++) acc = acc + H[k * m + i] * H[k * m + j];
     sys[e] = acc;
-    l[e] = 0.0;
+    lt[e] = 0.0;
     u[e] = 0.0;
   }
   for (int i = tid; i < m; i += kBlock) rhs[i] = beta * H[i];
@@ -616,32 +634,47 @@ __global__ __launch_bounds__(kBlock) void k_small_solve(const double *__restrict
     // row k of u (the diagonal entry first; l(k,k) = 1)
     for (int j = k + tid; j < m; j += kBlock) {
       double v = sys[k * m + j];
-      for (int i = 0; i < k; i++) v = v - l[k * m + i] * u[i * m + j];
+      for (int i = 0; i < k; i++) v = v - lt[i * m + k] * u[i * m + j];
       v = v / 1.0;
       u[k * m + j] = v;
     }
-    if (tid == 0) l[k * m + k] = 1.0;
+    if (tid == 0) lt[k * m + k] = 1.0;
     __syncthreads();
     const double ukk = u[k * m + k];
     for (int j = k + 1 + tid; j < m; j += kBlock) {
       double v = sys[j * m + k];
-      for (int i = 0; i < k; i++) v = v - l[j * m + i] * u[i * m + k];
+      for (int i = 0; i < k; i++) v = v - lt[i * m + j] * u[i * m + k];
       v = v / ukk;
-      l[j * m + k] = v;
+      lt[k * m + j] = v;
     }
     __syncthreads();
   }
-  if (tid == 0) {
+  if (m <= 64) {
+    if (tid < 64) {
+      // forward substitution in the first wavefront: lane i owns row i
+      const int i = tid;
+      double v = i < m ? rhs[i] : 0.0;
+      for (int j = 0; j < m; j++) {
+        const double pj = __shfl(v / 1.0, j, 64);  // partial(j) /= l(j,j), l(j,j) = 1
+        if (i > j && i < m) v = v - lt[j * m + i] * pj;
+      }
+      if (i < m) partial[i] = v / 1.0;
+    }
+  } else if (tid == 0) {
     for (int i = 0; i < m; i++) {
       double v = rhs[i];
-      for (int j = 0; j < i; j++) v = v - l[i * m + j] * partial[j];
-      v = v / l[i * m + i];
+      for (int j = 0; j < i; j++) v = v - lt[j * m + i] * partial[j];
+      v = v / lt[i * m + i];
       partial[i] = v;
     }
+  }
+  __syncthreads();
+  if (tid == 0) {
     for (int i = m - 1; i >= 0; i--) {
       double v = partial[i];
-      for (int j = i + 1; j < m; j++) v = v - u[i * m + j] * y[j];
+      for (int j = i + 1; j < m; j++) v = v - u[i * m + j] * ys[j];
       v = v / u[i * m + i];
+      ys[i] = v;
       y[i] = v;
     }
   }
@@ -1593,7 +1626,15 @@ void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *p
 
 void launch_small_solve(hipStream_t st, const double *H, const double *beta, int m, double *y,
                         double *work) {
-  hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(kBlock), 0, st, H, beta, m, y, work);
+  if (m <= kSmallLdsMaxM) {
+    const size_t lds = sizeof(double) * (3 * (size_t)m * m + 3 * (size_t)m);
+    static std::atomic<uint64_t> configured{0};
+    allow_lds(&k_small_solve<true>, sizeof(double) * (3 * (size_t)kSmallLdsMaxM * kSmallLdsMaxM + 3 * kSmallLdsMaxM),
+              configured, "LDS size of the reduced solve");
+    hipLaunchKernelGGL(k_small_solve<true>, dim3(1), dim3(kBlock), lds, st, H, beta, m, y, work);
+    return;
+  }
+  hipLaunchKernelGGL(k_small_solve<false>, dim3(1), dim3(kBlock), 0, st, H, beta, m, y, work);
 }
 
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x,

@@ -180,6 +180,14 @@ class GMRESSolver:
         check(capi.lib().kry_gmres_hessenberg_matrix(self.h, H.ctypes.data_as(_dp)))
         return H
 
+    def reduced_solve(self, H, beta):
+        """y of the reduced least-squares problem for a given (m+1) x m Hessenberg array."""
+        H, pH = _d(H)
+        assert H.shape == (self.m + 1, self.m)
+        y = np.empty(self.m)
+        check(capi.lib().kry_gmres_reduced_solve(self.h, pH, float(beta), y.ctypes.data_as(_dp)))
+        return y
+
     def prev_result(self):
         x = np.empty(self.n)
         check(capi.lib().kry_gmres_prev_result(self.h, x.ctypes.data_as(_dp)))
@@ -319,6 +327,10 @@ class ImplicitEuler:
 
     def cur_time(self):
         return capi.lib().kry_ie_time(self.h)
+
+    def use_graph(self, on):
+        """Replay the step through a captured hipGraph (True) or launch its kernels eagerly."""
+        check(capi.lib().kry_ie_use_graph(self.h, int(bool(on))))
 
     def set_generated_bands(self, on):
         """One-sweep steps evaluate the interior band entries from u and v (default) or read the stored bands."""

@@ -36,6 +36,23 @@ template <typename T> void bind_out_of_scope(py::module_ &m, const char *name, c
   py::class_<T>(m, name).def(py::init([msg](py::args, py::kwargs) -> T * { throw std::runtime_error(msg); }));
 }
 
+// timestep() is noexcept and reports a step that could not run as NaN (the reference's
+// only failure signal).  An exception raised by one of the Python callables is raised
+// again here, so that a typo in a lambda does not silently end the caller's time loop;
+// device and library failures stay NaN, with failed() / last_error() for the reason.
+template <typename TD> real step_from_python(TD &sim, const real dt) {
+  const real d = sim.timestep(dt);
+  if (sim.failed()) {
+    try {
+      sim.rethrow_failure();
+    } catch (const py::error_already_set &) {
+      throw;
+    } catch (...) {
+    }
+  }
+  return d;
+}
+
 template <typename SolverT> void bind_implicit_euler(py::module_ &m, const char *name) {
   using IE = ImplicitEuler<SecondOrderCentered, SolverT>;
   using P = std::pair<real, real>;
@@ -43,7 +60,7 @@ template <typename SolverT> void bind_implicit_euler(py::module_ &m, const char 
   py::class_<IE, std::shared_ptr<IE>, Base>(m, name)
       .def(py::init<const P, const P, const size_t, const size_t, std::function<triple(real, real)>,
                     const SecondOrderCentered &, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC>())
-      .def("timestep", &IE::timestep)
+      .def("timestep", &step_from_python<IE>)
       .def("system", &IE::sys)
       .def("solution", &IE::sol)
       .def("delta", &IE::delta)
@@ -157,7 +174,9 @@ PYBIND11_MODULE(krylov, module) {
   py::class_<Base, std::shared_ptr<Base>>(module, "_TimeDiscBase")
       .def("mesh", &Base::mesh)
       .def("space_disc", &Base::space_disc)
-      .def("cur_time", &Base::cur_time);
+      .def("cur_time", &Base::cur_time)
+      .def("failed", &Base::failed)           // extensions: why the last timestep() returned NaN
+      .def("last_error", &Base::last_error);
 
   bind_out_of_scope<OutOfScopeLU>(module, "ImplicitEulerLUSolver",
                                   "the dense LU solve of the whole N x N system is outside the device path");
@@ -169,7 +188,7 @@ PYBIND11_MODULE(krylov, module) {
     py::class_<AF, std::shared_ptr<AF>, Base>(module, "ImplicitEulerAFSolver")
         .def(py::init<const P, const P, const size_t, const size_t, std::function<triple(real, real)>,
                       const SecondOrderCentered &, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC, BC>())
-        .def("timestep", &AF::timestep)
+        .def("timestep", &step_from_python<AF>)
         .def("assemble_system_dx", &AF::assemble_system_dx)
         .def("assemble_system_dy", &AF::assemble_system_dy);
   }

@@ -5,7 +5,9 @@
 #ifndef KRYLOV_HOST_TIME_DISC_HPP_
 #define KRYLOV_HOST_TIME_DISC_HPP_
 
+#include <exception>
 #include <functional>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -60,7 +62,36 @@ public:
   real prandtl() const noexcept { return space.prandtl(); }
   real eckert() const noexcept { return space.eckert(); }
 
+  // timestep() is noexcept as in the reference (include/time_disc.hpp:277, :443), where
+  // failure only ever shows as NaN.  A step that could not run (a device or library
+  // failure, an exception out of a boundary function) likewise returns NaN; what happened
+  // is kept here.  No counterpart in the reference.
+  bool failed() const noexcept { return static_cast<bool>(failure_); }
+  const std::string &last_error() const noexcept { return last_error_; }
+  // Rethrows the failure of the last timestep(), if any (for callers that prefer
+  // exceptions, e.g. the Python module for exceptions raised by Python callables).
+  void rethrow_failure() const {
+    if (failure_) std::rethrow_exception(failure_);
+  }
+
 protected:
+  // Runs one step's host side; any exception becomes the NaN result.
+  template <typename F> real guarded_step(F &&step) noexcept {
+    failure_ = nullptr;
+    last_error_.clear();
+    try {
+      return step();
+    } catch (const std::exception &e) {
+      failure_ = std::current_exception();
+      try { last_error_ = e.what(); } catch (...) {}
+    } catch (...) {
+      failure_ = std::current_exception();
+    }
+    return q_nan;
+  }
+  std::exception_ptr failure_;
+  std::string last_error_;
+
   // Creates the device object for a solver with m iterations.
   void create_device(int m, int flags) {
     const int cx = cur_state.cells_x(), cy = cur_state.cells_y();
@@ -158,15 +189,17 @@ public:
   // functions are sampled for the time the NEXT step will start from (they
   // depend on position and time only); for Python callables that is the
   // expensive host part of a step, and it is hidden behind the device work.
-  real timestep(const real dt) {
-    this->push_bc_values();
-    krylov::check(kry_ie_timestep_async(this->ie_, dt), "kry_ie_timestep_async");
-    const real t_next = this->cur_time();
-    this->sample_bc_values(t_next, this->bc_scratch_);
-    real max_delta = 0.0;
-    krylov::check(kry_ie_last_max_delta(this->ie_, &max_delta), "kry_ie_last_max_delta");
-    this->stage_bc_values(this->bc_scratch_, t_next);
-    return max_delta;
+  real timestep(const real dt) noexcept {
+    return this->guarded_step([&]() -> real {
+      this->push_bc_values();
+      krylov::check(kry_ie_timestep_async(this->ie_, dt), "kry_ie_timestep_async");
+      const real t_next = this->cur_time();
+      this->sample_bc_values(t_next, this->bc_scratch_);
+      real max_delta = 0.0;
+      krylov::check(kry_ie_last_max_delta(this->ie_, &max_delta), "kry_ie_last_max_delta");
+      this->stage_bc_values(this->bc_scratch_, t_next);
+      return max_delta;
+    });
   }
 
   std::pair<const matrix &, const vector &> assemble_system(const real dt) {
@@ -223,11 +256,13 @@ public:
     this->apply_bcs();          // include/time_disc.hpp:440
   }
 
-  real timestep(const real dt) {
-    this->push_bc_values();
-    real max_delta = 0.0;
-    krylov::check(kry_ie_timestep_approx_fact(this->ie_, dt, &max_delta), "kry_ie_timestep_approx_fact");
-    return max_delta;
+  real timestep(const real dt) noexcept {
+    return this->guarded_step([&]() -> real {
+      this->push_bc_values();
+      real max_delta = 0.0;
+      krylov::check(kry_ie_timestep_approx_fact(this->ie_, dt, &max_delta), "kry_ie_timestep_approx_fact");
+      return max_delta;
+    });
   }
 
   const matrix &assemble_system_dy(const real dt, const int i) { return line_system(system_dy_, true, i, dt); }

@@ -158,6 +158,27 @@ def test_preconditioner_gmres_random(ctx, oracle):
         assert rel(v2, ref.subspace_vector(1)) <= 1e-12
 
 
+@pytest.mark.parametrize("m", [1, 2, 3, 10, 30, 50, 64, 65, 100])
+def test_reduced_solve_bit_exact_given_the_hessenberg_matrix(ctx, oracle, m):
+    """The m x m part of GMRESSolver::solve (include/solver.hpp:142-151 with
+    LUSolver::lu_decomp / solve, :34-96) on a given Hessenberg array: H^T H by
+    the generic triple loop, rhs = beta H(0,:), un-pivoted Doolittle LU, forward
+    and back substitution -- every entry by the reference's sequence of
+    operations, so y equals the CPU restatement's bit for bit (sizes below and
+    above the kernel's LDS limit of 64)."""
+    rng = np.random.default_rng(m)
+    H = np.triu(rng.uniform(-1.0, 1.0, (m + 1, m)), -1)       # upper Hessenberg
+    H[np.arange(1, m + 1), np.arange(m)] = rng.uniform(0.5, 2.0, m)  # sub-diagonal away from zero
+    H[np.arange(m), np.arange(m)] += 3.0
+    beta = float(rng.uniform(0.5, 5.0))
+    sys_ = oracle.dense_matmul(np.ascontiguousarray(H.T), H)   # dot(sys, transpose(H), H)
+    want = oracle.lu_solve(sys_, beta * H[0, :])
+    g = host.GMRESSolver(ctx, max(m + 1, 4), m)
+    got = g.reduced_solve(H, beta)
+    assert np.array_equal(got, want)
+    assert np.all(np.isfinite(got))
+
+
 def test_rejects_bad_arguments(ctx):
     A, b = simple_test(10)
     op = host.Operator.dense(ctx, A)
