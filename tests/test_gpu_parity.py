@@ -740,13 +740,15 @@ def test_full_size_properties(ctx, n, m):
 # ---- the line solver on its own ------------------------------------------------------
 
 @pytest.mark.parametrize("cx,cy", [(38, 18), (7, 62), (5, 64), (9, 126), (6, 130), (3, 200), (1030, 70), (2100, 66),
-                                   (4200, 30), (8200, 20), (8200, 70)])
+                                   (4200, 30), (8200, 20), (8200, 70), (7, 63), (40, 131), (9, 254), (6, 258),
+                                   (5, 700), (1030, 255), (300, 1021)])
 def test_line_preconditioner_bit_exact(ctx, oracle, cx, cy):
     """M^-1 v for the tridiagonal of the assembled system against
     SparseTriDiagSolver::solve (include/solver.hpp:246-273) run as ONE long
     recurrence over all unknowns, as the reference does: bit-exact.  The shapes
     cover line lengths below, at and above the 64-column chunk (partial and
-    full chunks, several chunks) and every lines-per-wavefront setting."""
+    full chunks, several chunks), even and odd, and every lines-per-wavefront
+    setting."""
     prob = problems.s_aniso(cx, cy)
     ref = oracle.ImplicitEuler(**prob, m=2, tdp=True)
     dev = host.ImplicitEuler(ctx, **prob, m=2, tdp=True)
