@@ -111,6 +111,11 @@ struct kry_ctx {
   ncclComm_t nccl = nullptr;
   // this device's copy of the file-scope scratch array (kry_apply_delta_noalloc)
   double *scratch = nullptr;
+  // Row blocks: a second stream on which a halo exchange travels while the rows that do
+  // not need it are worked on (created on first use; fork: main stream -> this one,
+  // join: back)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // RCCL entry points, resolved at run time so that single-GPU users never load
@@ -257,6 +262,8 @@ struct kry_gmres {
   // (fsigma[k] = 1 for vectors stored by the chain); valid while scaled is set
   double *fsigma = nullptr;
   bool scaled = false;
+  // row blocks: sweep the interior bands while the halo rows of the new vector travel
+  bool overlap_halo = true;
 };
 
 struct kry_ie {
@@ -361,6 +368,12 @@ static void ctx_free(kry_ctx *ctx) {
   }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   if (ctx->nccl) (void)rccl_api().CommDestroy(ctx->nccl);
+  if (ctx->comm_stream) {
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    (void)hipStreamDestroy(ctx->comm_stream);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -373,6 +386,8 @@ int kry_ctx_synchronize(kry_ctx *ctx) {
 
 void *kry_ctx_stream(kry_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+static int comm_stream_ready(kry_ctx *ctx);
+
 int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allreduce,
                      kry_sendrecv_fn sendrecv, void *user) {
   if (!ctx) return fail(KRY_ERR_INVALID, "ctx is NULL");
@@ -384,6 +399,10 @@ int kry_ctx_set_comm(kry_ctx *ctx, int rank, int nranks, kry_allreduce_fn allred
   ctx->allreduce = allreduce;
   ctx->sendrecv = sendrecv;
   ctx->comm_user = user;
+  if (nranks > 1) {
+    HIPCHK(hipSetDevice(ctx->device));
+    KCHK(comm_stream_ready(ctx));
+  }
   return KRY_OK;
 }
 
@@ -415,6 +434,7 @@ int kry_ctx_set_comm_rccl(kry_ctx *ctx, int rank, int nranks, const unsigned cha
   ctx->allreduce = nullptr;
   ctx->sendrecv = nullptr;
   ctx->comm_user = nullptr;
+  KCHK(comm_stream_ready(ctx));
   return KRY_OK;
 }
 
@@ -486,8 +506,10 @@ static int comm_allreduce(kry_ctx *ctx, double *buf, int64_t count, int op) {
 // rows hold P entries, nloc entries are owned.  The lower neighbour (rank-1)
 // receives my first row as its upper halo, the upper neighbour my last row.
 // Through RCCL all four transfers form one group (one launch on the stream).
-static int comm_halo(kry_ctx *ctx, double *local, int64_t P, int64_t nloc) {
+// st: the stream the transfers are ordered on (nullptr: the context's stream).
+static int comm_halo(kry_ctx *ctx, double *local, int64_t P, int64_t nloc, hipStream_t st = nullptr) {
   if (ctx->nranks == 1) return KRY_OK;
+  if (!st) st = ctx->stream;
   const int down = ctx->rank > 0 ? ctx->rank - 1 : -1;
   const int up = ctx->rank + 1 < ctx->nranks ? ctx->rank + 1 : -1;
   if (ctx->nccl) {
@@ -495,21 +517,30 @@ static int comm_halo(kry_ctx *ctx, double *local, int64_t P, int64_t nloc) {
     NCCLCHK(api.GroupStart());
     ncclResult_t r = ncclSuccess;
     if (down >= 0) {
-      if (r == ncclSuccess) r = api.Send(local, (size_t)P, ncclDouble, down, ctx->nccl, ctx->stream);
-      if (r == ncclSuccess) r = api.Recv(local - P, (size_t)P, ncclDouble, down, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.Send(local, (size_t)P, ncclDouble, down, ctx->nccl, st);
+      if (r == ncclSuccess) r = api.Recv(local - P, (size_t)P, ncclDouble, down, ctx->nccl, st);
     }
     if (up >= 0) {
-      if (r == ncclSuccess) r = api.Send(local + nloc - P, (size_t)P, ncclDouble, up, ctx->nccl, ctx->stream);
-      if (r == ncclSuccess) r = api.Recv(local + nloc, (size_t)P, ncclDouble, up, ctx->nccl, ctx->stream);
+      if (r == ncclSuccess) r = api.Send(local + nloc - P, (size_t)P, ncclDouble, up, ctx->nccl, st);
+      if (r == ncclSuccess) r = api.Recv(local + nloc, (size_t)P, ncclDouble, up, ctx->nccl, st);
     }
     const ncclResult_t e = api.GroupEnd();
     if (r != ncclSuccess) return fail(KRY_ERR_HIP, "ncclSend/ncclRecv: %s", api.GetErrorString(r));
     if (e != ncclSuccess) return fail(KRY_ERR_HIP, "ncclGroupEnd: %s", api.GetErrorString(e));
     return KRY_OK;
   }
-  int rc = ctx->sendrecv(ctx->comm_user, local, down, local + nloc, up, P, (void *)ctx->stream);
-  if (rc == 0) rc = ctx->sendrecv(ctx->comm_user, local + nloc - P, up, local - P, down, P, (void *)ctx->stream);
+  int rc = ctx->sendrecv(ctx->comm_user, local, down, local + nloc, up, P, (void *)st);
+  if (rc == 0) rc = ctx->sendrecv(ctx->comm_user, local + nloc - P, up, local - P, down, P, (void *)st);
   if (rc != 0) return fail(KRY_ERR_STATE, "sendrecv callback failed with %d", rc);
+  return KRY_OK;
+}
+
+// The second stream and its two events, created on first use.
+static int comm_stream_ready(kry_ctx *ctx) {
+  if (ctx->comm_stream) return KRY_OK;
+  HIPCHK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   return KRY_OK;
 }
 
@@ -793,6 +824,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   // groups is 16) and 1/32 of the reductions (all-reduces on several ranks) of the plain
   // chain.
   g->kblock = kMgsBlock;
+  if (const char *e = getenv("KRY_HALO_OVERLAP")) g->overlap_halo = atoi(e) != 0;  // experimentation knob
   if (const char *e = getenv("KRY_MGS_BLOCK")) {  // experimentation knob, same range as the setter
     const int k = atoi(e);
     if (mgs_block_supported(k)) g->kblock = k;
@@ -1219,12 +1251,27 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
           launch_arnoldi_close(st, i, b, basis(g, 0), g->ld, g->fcoef, n, op->cols, k0, P, true, g->fparts, &np);
           if (n == P) break;
         }
-        KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
       }
-      {
+      const BandGen *gen = op->has_gen && op->use_gen ? &op->gen : nullptr;
+      if (ranks && g->overlap_halo && fused_bands_splittable(i, op->rows, op->cols)) {
+        // The neighbours' rows of the new vector travel on the second stream while the bands of
+        // rows that do not touch them are swept; the first and the last band follow.
+        kry_ctx *c = g->ctx;
+        KCHK(comm_stream_ready(c));
+        HIPCHK(hipEventRecord(c->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+        KCHK(comm_halo(c, basis(g, i + 1), P, n, c->comm_stream));
+        HIPCHK(hipEventRecord(c->ev_join, c->comm_stream));
+        ScopedKernelTimer t(c, KRY_K_FUSED);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, true, gen,
+                             kSweepInterior);
+        HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, true, gen,
+                             kSweepEdges);
+      } else {
+        if (ranks) KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
-        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks,
-                             op->has_gen && op->use_gen ? &op->gen : nullptr);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks, gen);
       }
       KCHK(fused_totals(g, 2 * i + 4, np));
     } else {

@@ -62,10 +62,16 @@ __device__ __forceinline__ void sum_parts_multi(const double *__restrict__ part,
   __syncthreads();
 }
 
-// Block-level reduction of NQ accumulators into part[q * gridDim.x + blockIdx.x].
+// Block-level reduction of NQ accumulators into part[q * np + wg] (by default: one slot per
+// workgroup of the launch; a launch that covers part of a larger set of workgroups passes
+// its workgroup's number in that set and the size of the set).
 template <int NQ>
 __device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? NQ : 1], double *red /* LDS NQ*4 */,
-                                                    double *__restrict__ part) {
+                                                    double *__restrict__ part, int wg = -1, int np = 0) {
+  if (wg < 0) {
+    wg = blockIdx.x;
+    np = gridDim.x;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
@@ -77,7 +83,7 @@ __device__ __forceinline__ void reduce_store_multi(const double (&acc)[NQ > 0 ? 
     double t = red[threadIdx.x * (kBlock / 64)];
 #pragma unroll
     for (int i = 1; i < kBlock / 64; i++) t += red[threadIdx.x * (kBlock / 64) + i];
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
+    part[(size_t)threadIdx.x * np + wg] = t;
   }
 }
 

@@ -66,6 +66,10 @@ struct FusedGeom {
   int rows, P;     // padded grid: rows x P, unknown k = row * P + column
   int W, nstrips;  // owned columns per strip, strips per row
   int R, nbands;   // rows per band, bands
+  // A launch may cover a subset of the bands: workgroup b of the launch works on band
+  // band_first + (b / nstrips) * band_step.  Its partial sums go to the slot it would have in
+  // a launch over all bands, so the subsets' launches fill one array between them.
+  int band_first = 0, band_step = 1;
 };
 
 // Stencil row sum in ascending column order starting from +0.0, as k_spmv_stencil.
@@ -155,7 +159,7 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
 // either side of the strip and a second halo row at either end of the band (s_NV only).
 // s_halo: the rows in front of the first / behind the last grid row exist in memory
 // (a neighbouring rank's rows of s_NV, zeros beyond the mesh).
-// part layout (q * gridDim.x + workgroup): q <= NV: <t, s_q>;  NV+1: <t, u>;
+// part layout (q * nstrips * nbands + band * nstrips + strip): q <= NV: <t, s_q>;  NV+1: <t, u>;
 // NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>   (t = A u).
 // GEN: the band entries of interior cells are evaluated from the recipe `gen` (velocity
 // snapshots; the operations of k_offdiag, so the same bits) and those of ghost rows and
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   double *red = sring + 4 * kBlock;                 // NQ x 4
   const int t = threadIdx.x;
   const int tm = t > 0 ? t - 1 : 0, tp = t + 1 < kBlock ? t + 1 : kBlock - 1;
-  const int strip = blockIdx.x % geo.nstrips, band = blockIdx.x / geo.nstrips;
+  const int strip = blockIdx.x % geo.nstrips, band = geo.band_first + (blockIdx.x / geo.nstrips) * geo.band_step;
   const int cs = strip * geo.W;
   const int ce = cs + geo.W < geo.P ? cs + geo.W : geo.P;
   const int wown = ce - cs;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     if (rr + 1 > re) break;
     round(rr + 1, qb, qa);
   }
-  reduce_store_multi<NQ>(acc, red, part);
+  reduce_store_multi<NQ>(acc, red, part, band * geo.nstrips + strip, geo.nstrips * geo.nbands);
 }
 
 // The same sweep by a workgroup of 512 threads whose two halves share the columns of the
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   const int half = threadIdx.x >> 8, t = threadIdx.x & (kBlock - 1);
   const int lane = t & 63, wv = t >> 6;
   const int tm = t > 0 ? t - 1 : 0, tp = t + 1 < kBlock ? t + 1 : kBlock - 1;
-  const int strip = blockIdx.x % geo.nstrips, band = blockIdx.x / geo.nstrips;
+  const int strip = blockIdx.x % geo.nstrips, band = geo.band_first + (blockIdx.x / geo.nstrips) * geo.band_step;
   const int cs = strip * geo.W;
   const int ce = cs + geo.W < geo.P ? cs + geo.W : geo.P;
   const int wown = ce - cs;
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     double tot = red[threadIdx.x * 4];
 #pragma unroll
     for (int i = 1; i < 4; i++) tot += red[threadIdx.x * 4 + i];
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+    part[(size_t)threadIdx.x * (geo.nstrips * geo.nbands) + (band * geo.nstrips + strip)] = tot;
   }
 }
 
@@ -834,7 +838,7 @@ FusedGeom fused_geom(int rows, int P, int nv) {
 template <int NV, bool GEN>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
                     int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
-                    const double *u_halo, int s_halo) {
+                    const double *u_halo, int s_halo, int launch_bands) {
   constexpr size_t lds =
       sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 4) * (kBlock / 64));
   static_assert(lds <= 160 * 1024, "LDS of one compute unit");
@@ -848,12 +852,12 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
       static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
       static std::atomic<uint64_t> configured2{0};
       allow_lds(&k_arnoldi_split<NV, GEN>, lds2, configured2, "LDS size of the 512-thread one-sweep kernel");
-      hipLaunchKernelGGL((k_arnoldi_split<NV, GEN>), dim3(geo.nstrips * geo.nbands), dim3(kSplitBlock), lds2, st, geo, b,
+      hipLaunchKernelGGL((k_arnoldi_split<NV, GEN>), dim3(geo.nstrips * launch_bands), dim3(kSplitBlock), lds2, st, geo, b,
                          gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
       return;
     }
   }
-  hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN>), dim3(geo.nstrips * geo.nbands), dim3(kBlock), lds, st, geo, b, gen, V,
+  hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN>), dim3(geo.nstrips * launch_bands), dim3(kBlock), lds, st, geo, b, gen, V,
                      ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
 }
 
@@ -880,16 +884,16 @@ void launch_close_t(hipStream_t st, const CloseArgs &a) {
 template <int NV = kFusedMaxM - 1>
 struct FusedTable {
   static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen *gen, const double *V,
-                    int64_t ld, const double *coef, double *part, bool u_halo, int s_halo) {
+                    int64_t ld, const double *coef, double *part, bool u_halo, int s_halo, int launch_bands) {
     if (nv == NV) {
       double *u_out = const_cast<double *>(V) + (int64_t)(NV + 1) * ld;
       const double *uh = u_halo ? u_out : nullptr;
       if (gen)
-        launch_fused_t<NV, true>(st, geo, b, *gen, V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo);
+        launch_fused_t<NV, true>(st, geo, b, *gen, V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo, launch_bands);
       else
-        launch_fused_t<NV, false>(st, geo, b, BandGen(), V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo);
+        launch_fused_t<NV, false>(st, geo, b, BandGen(), V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo, launch_bands);
     } else {
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, gen, V, ld, coef, part, u_halo, s_halo);
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, gen, V, ld, coef, part, u_halo, s_halo, launch_bands);
     }
   }
   static void close(int nv, hipStream_t st, const CloseArgs &a) {
@@ -903,7 +907,7 @@ struct FusedTable {
 template <>
 struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const BandGen *, const double *, int64_t,
-                    const double *, double *, bool, int) {}
+                    const double *, double *, bool, int, int) {}
   static void close(int, hipStream_t, const CloseArgs &) {}
 };
 
@@ -922,11 +926,26 @@ int fused_parts(int rows, int cols) {
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen) {
-  const FusedGeom g = fused_geom(rows, cols, nv);
-  FusedTable<>::sweep(nv, st, g, b, gen, V, ld, coef, part, has_halo, has_halo ? 1 : 0);
+                          const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen, int which) {
+  FusedGeom g = fused_geom(rows, cols, nv);
   *nparts = g.nstrips * g.nbands;
+  int launch_bands = g.nbands;
+  if (which == kSweepInterior) {
+    if (g.nbands < 3) return;  // nothing between the first and the last band
+    g.band_first = 1;
+    launch_bands = g.nbands - 2;
+  } else if (which == kSweepEdges) {
+    if (g.nbands < 3) {
+      launch_bands = g.nbands;  // no interior launch has run: everything here
+    } else {
+      g.band_step = g.nbands - 1;
+      launch_bands = 2;
+    }
+  }
+  FusedTable<>::sweep(nv, st, g, b, gen, V, ld, coef, part, has_halo, has_halo ? 1 : 0, launch_bands);
 }
+
+bool fused_bands_splittable(int nv, int rows, int cols) { return fused_geom(rows, cols, nv).nbands >= 3; }
 
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
                           int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts) {

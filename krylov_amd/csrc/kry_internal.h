@@ -180,9 +180,16 @@ int get_split_from();
 // halos of slots nv and nv + 1 (a neighbouring rank's rows, zeros beyond the mesh)
 // instead of being treated as zero.
 // gen != nullptr: interior band entries are evaluated from the recipe instead of being read.
+// which: all bands of rows in one launch, or only the bands that do not touch the rows in front
+// of / behind the local grid (they need no neighbour's row of the new vector and can run while
+// those rows are still travelling), or only the first and the last band (everything if there
+// are fewer than three bands).  The partial sums of an interior and an edge launch together
+// fill the array of an all-bands launch.
+enum { kSweepAll = 0, kSweepInterior = 1, kSweepEdges = 2 };
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo,
-                          const BandGen *gen = nullptr);
+                          const BandGen *gen = nullptr, int which = kSweepAll);
+bool fused_bands_splittable(int nv, int rows, int cols);
 // The update alone on the cnt unknowns from k0 on (n: unknowns of the local vector):
 // the new vector in slot nv + 1 and its squared norm in part.
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,

@@ -108,6 +108,7 @@ class TorchComm:
         self.host = None if self.device_native else HostCollectives(group)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.ExternalStream(ctx.stream, device=self.device)
+        self._streams = {int(ctx.stream or 0): self.stream}
         self._tensors = {}
         self.calls = {"allreduce": 0, "sendrecv": 0}
         self._ar = capi.ALLREDUCE_FN(self._allreduce)
@@ -115,6 +116,16 @@ class TorchComm:
         capi.check(capi.lib().kry_ctx_set_comm(ctx.h, self.rank, self.nranks,
                                                C.cast(self._ar, C.c_void_p), C.cast(self._sr, C.c_void_p), None))
         ctx._comm = self  # keep the callbacks alive as long as the context
+
+    def _stream(self, handle):
+        """torch view of the hipStream_t the library hands to a callback (its own stream, or
+        the second one on which a halo exchange overlaps with compute)."""
+        key = int(handle or 0)
+        st = self._streams.get(key)
+        if st is None:
+            st = self.torch.cuda.ExternalStream(key, device=self.device)
+            self._streams[key] = st
+        return st
 
     def _tensor(self, ptr, count):
         key = (ptr, count)
@@ -128,7 +139,7 @@ class TorchComm:
         try:
             self.calls["allreduce"] += 1
             t = self._tensor(ptr, count)
-            with self.torch.cuda.stream(self.stream):
+            with self.torch.cuda.stream(self._stream(stream)):
                 if self.device_native:
                     rop = self.dist.ReduceOp.MAX if op == capi.REDUCE_MAX else self.dist.ReduceOp.SUM
                     self.dist.all_reduce(t, op=rop, group=self.group)
@@ -144,7 +155,7 @@ class TorchComm:
     def _sendrecv(self, user, send_ptr, send_peer, recv_ptr, recv_peer, count, stream):
         try:
             self.calls["sendrecv"] += 1
-            with self.torch.cuda.stream(self.stream):
+            with self.torch.cuda.stream(self._stream(stream)):
                 if self.device_native:
                     ops = []
                     if recv_peer >= 0:

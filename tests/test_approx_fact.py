@@ -87,7 +87,15 @@ def test_reference_smoke_runs_converge(oracle, cx, cy):
 def test_device_steps_bit_exact(ctx, oracle, name, args):
     """Twenty steps on the device against the restatement: every operation is
     element-wise or a sequential line recurrence in the reference's order, so
-    temperatures, per-step maxima and the line systems agree bit for bit."""
+    temperatures, per-step maxima and the line systems agree bit for bit.
+
+    PARITY UNPINNED for the transient: the reference's own tests of this class
+    assert only the boundary rows of the line systems (src/test.cpp:643-648,
+    restated in test_assemble_sys_boundary_rows above; its interior check at
+    :649-654 is stale and fails against the reference itself) and otherwise
+    print (:591-631).  The restatement's transient is therefore pinned by
+    nothing but those rows and its steady state; this test shows device ==
+    restatement, not restatement == reference."""
     from krylov_amd import host
     prob = af_default_problem(*args) if name == "af_default" else getattr(problems, name)(*args)
     ref = oracle.ApproxFact(**prob)

@@ -21,6 +21,8 @@ def rel(a, b):
     (2, "prob1", 2, 5, 3, 0),
     (3, "s_iso", 20, 300, 20, 0),  # rows wider than one strip of the one-sweep kernels
     (3, "s_iso", 1, 40, 5, 0),     # one grid row per rank
+    (2, "s_iso", 400, 40, 12, 0),  # six bands of rows per rank: interior bands swept while the halo rows travel
+    (3, "s_iso", 330, 270, 20, 0),  # three bands, two strips, the 512-thread kernel from step 14 on
 ])
 def test_slabs_match_single_rank(tmp_path, ctx, oracle, nranks, name, cx, cy, m, tdp):
     steps = 3
@@ -111,3 +113,21 @@ def test_bench_contract_two_ranks_shared_gpu(tmp_path):
     # the row blocks run the one-sweep Arnoldi kernels (8 of the 10 steps per cycle; the last is the closing sweep)
     assert d["kernels"]["arnoldi_fused"]["launches"] == 2 * 7
     assert abs(d["value"] - 10 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("nranks,cx,cy,m", [(2, 400, 40, 12), (3, 330, 270, 20)])
+def test_halo_overlap_changes_no_bit(tmp_path, monkeypatch, nranks, cx, cy, m):
+    """On row blocks the one-sweep steps sweep the interior bands of rows while the
+    neighbours' rows of the new vector travel on a second stream, then the first
+    and the last band: two launches that fill one array of partial sums.  Every
+    result bit must equal the run with one launch after the exchange
+    (KRY_HALO_OVERLAP=0)."""
+    runs = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("KRY_HALO_OVERLAP", overlap)
+        out = tmp_path / ("res%s.npz" % overlap)
+        launch(nranks, ["hip", out, "s_iso", cx, cy, m, 0, 3], timeout=600)
+        runs.append(np.load(out))
+    a, b = runs
+    assert np.array_equal(a["deltas"], b["deltas"])
+    assert np.array_equal(a["T"], b["T"], equal_nan=True) and np.array_equal(a["D"], b["D"], equal_nan=True)
