@@ -31,8 +31,11 @@ def run(args, world, rank, local_rank, out_stream=None):
 
     def selfcheck(c):
         capi.check(capi.lib().kry_ctx_comm_selftest(c.h))
-        prob, mm = problems.s_iso(96, 64), 8
-        part = host.ImplicitEuler(c, **prob, m=mm, row_range=partition_rows(98, world)[rank])
+        # rows enough for three bands of rows per rank, so that the one-sweep steps take the
+        # path on which the halo rows travel while the interior bands are swept
+        rows = max(96 * world, 96)
+        prob, mm = problems.s_iso(rows, 64), 8
+        part = host.ImplicitEuler(c, **prob, m=mm, row_range=partition_rows(rows + 2, world)[rank])
         one = host.ImplicitEuler(host.Context(device), **prob, m=mm)
         err = 0.0
         for _ in range(2):
@@ -40,22 +43,36 @@ def run(args, world, rank, local_rank, out_stream=None):
             err = max(err, abs(a - b) / abs(b))
         return err
 
+    # candidates, tried in order until all ranks pass the check: the library's own RCCL calls
+    # with and without the overlapped halo exchange, then the torch.distributed callbacks
     want = os.environ.get("KRY_DIST_COMM", "rccl" if backend == "nccl" else "torch")
-    comm_kind, check_err, ctx, comm = None, None, None, None
-    for kind in ([want] if want == "torch" else [want, "torch"]):
+    overlap_pref = os.environ.get("KRY_HALO_OVERLAP", "1")
+    candidates = [(want, overlap_pref)]
+    if overlap_pref != "0":
+        candidates.append((want, "0"))
+    if want != "torch":
+        candidates.append(("torch", "0"))
+    comm_kind, check_err, ctx, comm, overlap = None, None, None, None, None
+    for kind, ov in candidates:
+        os.environ["KRY_HALO_OVERLAP"] = ov  # read when a solver is created
         try:
-            ctx, comm = make(kind)
+            if ctx is None or kind != getattr(ctx, "_kind", None):
+                ctx, comm = make(kind)
+                ctx._kind = kind
             check_err = selfcheck(ctx)
             ok = check_err <= 1e-9
-        except Exception as e:  # noqa: BLE001 - any failure means: try the other transport
+        except Exception as e:  # noqa: BLE001 - any failure means: try the next candidate
             if rank == 0:
-                print("krylov_amd.dist_bench: %s collectives unusable: %r" % (kind, e), file=sys.stderr, flush=True)
+                print("krylov_amd.dist_bench: %s collectives (halo overlap %s) unusable: %r" % (kind, ov, e),
+                      file=sys.stderr, flush=True)
             ok = False
+            ctx = None
         flag = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            comm_kind = kind
+            comm_kind, overlap = kind, ov != "0"
             break
+        ctx = None
     if comm_kind is None:
         raise RuntimeError("no working collectives (self-check error %r)" % (check_err,))
     n_side, m, dt = args.mesh, args.m, args.dt
@@ -149,6 +166,7 @@ def run(args, world, rank, local_rank, out_stream=None):
             round(elapsed / args.steps * 1e3 - kernel_ms / args.steps, 2),
             "graph": bool(graph),
             "collectives": comm_kind, "collectives_selfcheck_rel_err": check_err,
+            "halo_exchange_overlapped_with_interior_bands": bool(overlap),
             "collectives_per_step": {k: (v // args.steps if v is not None else None) for k, v in comm.calls.items()},
             "kernels": kernels,
             "roofline": roofline,
