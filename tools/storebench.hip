@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -23,7 +24,9 @@ __device__ __forceinline__ void store_pol(double *p, double v) {
 }
 
 // BURST rows of the result are kept in registers and stored together
-template <int K, int POL, int BURST, bool TILED = false>
+// LAYOUT of the written vector: 0 the grid's own, 1 a workgroup's rows contiguous, 2 every row of a workgroup onto the same 2 KB
+// (the stores are issued, the bytes never leave the cache: separates instruction-stream cost from memory-system cost)
+template <int K, int POL, int BURST, int TILED = 0>
 __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
                                              int R, double *__restrict__ out, double *__restrict__ Wr) {
   const int t = threadIdx.x;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long 
       if ((j == BURST - 1 || rr == re - 1) && ok) {
 #pragma unroll
         for (int q = 0; q < BURST; q++)
-          if (q <= j) store_pol<POL>(TILED ? &Wr[((long)strip * rows + (rr - j + q)) * 256 + t] : &Wr[(long)(rr - j + q) * P + c], hold[q]);
+          if (q <= j) store_pol<POL>(TILED == 2 ? &Wr[(long)blockIdx.x * 256 + t] : TILED == 1 ? &Wr[((long)strip * rows + (rr - j + q)) * 256 + t] : &Wr[(long)(rr - j + q) * P + c], hold[q]);
       }
     }
   }
@@ -64,7 +67,74 @@ __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long 
   if (s == 12345.678) out[blockIdx.x] = s;
 }
 
-template <int K, int POL, int BURST, bool TILED = false>
+// Latency probe: per row all K loads are issued and waited for (timed), every 16 rows 16 non-temporal stores are issued
+// and waited for (timed).  out[0..3] receive sums of cycles and counts over all waves (lane 0 of each).
+template <int K, int TILED>
+__global__ __launch_bounds__(256) void strip_lat(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
+                                                 int R, unsigned long long *__restrict__ out, double *__restrict__ Wr) {
+  const int t = threadIdx.x;
+  const int strip = blockIdx.x % nstrips, band = blockIdx.x / nstrips;
+  const int c = strip * W + t;
+  const bool ok = c < P && t < W;
+  const int rs = band * R, re = rs + R < rows ? rs + R : rows;
+  double hold[16];
+  double tot = 0.0;
+  unsigned long long tl = 0, ts = 0, nl = 0, ns = 0;
+  for (int rr = rs; rr < re; rr++) {
+    const long idx = (long)rr * P + c;
+    double s = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t0 = clock64();
+    if (ok) {
+      double v[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = __builtin_nontemporal_load(&V[k * ld + idx]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < K; k++) s += v[k];
+    }
+    const long long t1 = clock64();
+    tl += t1 - t0; nl++;
+    tot += s;
+    const int j = (rr - rs) % 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) if (q == j) hold[q] = s;
+    if (j == 15 || rr == re - 1) {
+      const long long t2 = clock64();
+      if (ok) {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          if (q <= j) __builtin_nontemporal_store(hold[q], TILED == 2 ? &Wr[(long)blockIdx.x * 256 + t] : &Wr[(long)(rr - j + q) * P + c]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long t3 = clock64();
+      ts += t3 - t2; ns++;
+    }
+  }
+  if ((t & 63) == 0) {
+    atomicAdd(&out[0], tl); atomicAdd(&out[1], nl); atomicAdd(&out[2], ts); atomicAdd(&out[3], ns);
+  }
+  if (tot == 12345.678) Wr[0] = tot;
+}
+
+template <int K, int TILED>
+void run_lat(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr) {
+  const int W = 249, nstrips = (P + W - 1) / W;
+  const int nb = 1024 / nstrips;
+  const int R = (rows + nb - 1) / nb, nbands = (rows + R - 1) / R;
+  unsigned long long *o = (unsigned long long *)out, h[4];
+  CHECK(hipMemset(o, 0, 32));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL((strip_lat<K, TILED>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, o, Wr);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  CHECK(hipMemcpy(h, o, 32, hipMemcpyDeviceToHost));
+  printf("K=%2d latency probe %-12s %8.1f us: a row of %d loads waited %.0f clocks, a burst of 16 stores waited %.0f clocks (shader clocks)\n", K, name,
+         ms * 1e3, K, (double)h[0] / h[1], (double)h[2] / h[3]);
+}
+
+template <int K, int POL, int BURST, int TILED = 0>
 void run(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr) {
   const int W = 249, nstrips = (P + W - 1) / W;
   const int nb = 1024 / nstrips;
@@ -78,7 +148,7 @@ void run(const char *name, const double *V, long ld, int rows, int P, double *ou
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipGetLastError());
   const double bytes = 8.0 * (K + (POL > 0 ? 1 : 0)) * (double)rows * P;
-  printf("K=%2d burst %2d  %-14s %8.1f us %7.1f GB/s\n", K, BURST, name, ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9);
+  printf("K=%2d burst %2d  %-32s %8.1f us %7.1f GB/s\n", K, BURST, name, ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9);
 }
 
 template <int K, int BURST>
@@ -94,23 +164,71 @@ void all(const double *V, long ld, int rows, int P, double *out, double *Wr) {
   run<K, 8, BURST>("sc0 nt", V, ld, rows, P, out, Wr);
 }
 
-int main() {
+int main(int argc, char **argv) {
   const int rows = 8194, P = 8194;
   const long n = (long)rows * P, ld = (n + 31) / 32 * 32;
   double *V, *out, *Wr;
   CHECK(hipMalloc((void **)&V, sizeof(double) * ld * 32)); CHECK(hipMemset(V, 0, sizeof(double) * ld * 32));
   CHECK(hipMalloc((void **)&out, sizeof(double) * 65536));
   CHECK(hipMalloc((void **)&Wr, sizeof(double) * ld * 2)); CHECK(hipMemset(Wr, 0, sizeof(double) * ld * 2));
+  if (argc > 1 && !strcmp(argv[1], "pmc")) {  // few distinct kernels for a counter pass
+    run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<16, 1, 16>("plain", V, ld, rows, P, out, Wr);
+    run<16, 2, 16, 2>("nt same 2 KB", V, ld, rows, P, out, Wr);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "memtype")) {  // the written vector, then the read vectors as well, in uncached / fine-grained memory
+    double *Wu, *Wf, *Vu;
+    CHECK(hipExtMallocWithFlags((void **)&Wu, sizeof(double) * ld * 2, hipDeviceMallocUncached)); CHECK(hipMemset(Wu, 0, sizeof(double) * ld * 2));
+    CHECK(hipExtMallocWithFlags((void **)&Wf, sizeof(double) * ld * 2, hipDeviceMallocFinegrained)); CHECK(hipMemset(Wf, 0, sizeof(double) * ld * 2));
+    CHECK(hipExtMallocWithFlags((void **)&Vu, sizeof(double) * ld * 16, hipDeviceMallocUncached)); CHECK(hipMemset(Vu, 0, sizeof(double) * ld * 16));
+    run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<16, 2, 16>("nt -> uncached", V, ld, rows, P, out, Wu);
+    run<16, 1, 16>("plain -> uncached", V, ld, rows, P, out, Wu);
+    run<16, 2, 16>("nt -> fine-grained", V, ld, rows, P, out, Wf);
+    run<16, 1, 16>("plain -> fine-grained", V, ld, rows, P, out, Wf);
+    run<16, 0, 16>("uncached reads only", Vu, ld, rows, P, out, Wr);
+    run<16, 2, 16>("uncached reads, nt -> uncached", Vu, ld, rows, P, out, Wu);
+    run<4, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<4, 2, 16>("nt -> uncached", V, ld, rows, P, out, Wu);
+    run<4, 1, 16>("plain -> uncached", V, ld, rows, P, out, Wu);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "lat")) {
+    run_lat<4, 0>("grid", V, ld, rows, P, out, Wr); run_lat<4, 2>("same 2 KB", V, ld, rows, P, out, Wr);
+    run_lat<16, 0>("grid", V, ld, rows, P, out, Wr); run_lat<16, 2>("same 2 KB", V, ld, rows, P, out, Wr);
+    run_lat<32, 0>("grid", V, ld, rows, P, out, Wr); run_lat<32, 2>("same 2 KB", V, ld, rows, P, out, Wr);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "same")) {
+    run<4, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<4, 2, 16, 2>("nt same 2 KB", V, ld, rows, P, out, Wr);
+    run<4, 1, 16, 2>("plain same 2 KB", V, ld, rows, P, out, Wr);
+    run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<16, 2, 16, 2>("nt same 2 KB", V, ld, rows, P, out, Wr);
+    run<16, 1, 16, 2>("plain same 2 KB", V, ld, rows, P, out, Wr);
+    run<16, 1, 1, 2>("plain same 2 KB", V, ld, rows, P, out, Wr);
+    run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<32, 2, 16, 2>("nt same 2 KB", V, ld, rows, P, out, Wr);
+    run<32, 1, 16, 2>("plain same 2 KB", V, ld, rows, P, out, Wr);
+    return 0;
+  }
   run<4, 0, 16>("reads only", V, ld, rows, P, out, Wr);
   run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
-  run<4, 2, 16, true>("nt tiled", V, ld, rows, P, out, Wr);
-  run<4, 1, 16, true>("plain tiled", V, ld, rows, P, out, Wr);
+  run<4, 2, 16, 1>("nt tiled", V, ld, rows, P, out, Wr);
+  run<4, 1, 16, 1>("plain tiled", V, ld, rows, P, out, Wr);
   run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
   run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
-  run<16, 2, 16, true>("nt tiled", V, ld, rows, P, out, Wr);
-  run<16, 2, 1, true>("nt tiled", V, ld, rows, P, out, Wr);
+  run<16, 2, 16, 1>("nt tiled", V, ld, rows, P, out, Wr);
+  run<16, 2, 1, 1>("nt tiled", V, ld, rows, P, out, Wr);
   run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
   run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
-  run<32, 2, 16, true>("nt tiled", V, ld, rows, P, out, Wr);
+  run<32, 2, 16, 1>("nt tiled", V, ld, rows, P, out, Wr);
   return 0;
 }
