@@ -879,21 +879,14 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_factor(const double *__restrict__
 // out = M^-1 sol for every line (include/solver.hpp:255-271: forward
 // elimination, then back substitution).  sol and out may be the same array.
 template <int LPW>
-__global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ lo,
-                                                      const double *__restrict__ dd,
-                                                      const double *__restrict__ ud,
-                                                      const double *sol, double *out,
-                                                      int64_t nlines, int64_t L,
-                                                      const int *__restrict__ stop) {
-  if (stopped(stop)) return;
+__device__ __forceinline__ void tdp_apply_lines(TdpTile<LPW> (&ts)[2], TdpTile<LPW> &ta, TdpTile<LPW> &td,
+                                                const double *__restrict__ lo, const double *__restrict__ dd,
+                                                const double *__restrict__ ud, const double *sol, double *out,
+                                                int64_t line0, int nl, int64_t L, int lane) {
   // The running right-hand side has two tiles: chunk c is walked in one while chunk c-1
   // leaves the other.  Its stores are issued before the loads of chunk c+1, so the wait
   // for those loads at the top of the next round (the memory counter retires in order)
   // never stalls on stores that were issued after them.
-  __shared__ TdpTile<LPW> ts[2], ta, td;
-  const int lane = threadIdx.x;
-  const int64_t line0 = (int64_t)blockIdx.x * LPW;
-  const int nl = (int)((nlines - line0) < LPW ? (nlines - line0) : LPW);
   const int64_t nchunk = (L + kTdpC - 1) / kTdpC;
   double rs[LPW], ra[LPW], rd[LPW];
   tdp_fetch<LPW>(rs, sol, line0, nl, L, lane, 0.0);
@@ -949,6 +942,259 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ 
     __syncthreads();
   }
   tdp_flush<LPW>(ts[0], out, line0, nl, L, lane, lane);
+}
+
+template <int LPW>
+__global__ __launch_bounds__(kTdpC) void k_tdp_apply(const double *__restrict__ lo,
+                                                      const double *__restrict__ dd,
+                                                      const double *__restrict__ ud,
+                                                      const double *sol, double *out,
+                                                      int64_t nlines, int64_t L,
+                                                      const int *__restrict__ stop) {
+  if (stopped(stop)) return;
+  __shared__ TdpTile<LPW> ts[2], ta, td;
+  const int64_t line0 = (int64_t)blockIdx.x * LPW;
+  const int nl = (int)((nlines - line0) < LPW ? (nlines - line0) : LPW);
+  tdp_apply_lines<LPW>(ts, ta, td, lo, dd, ud, sol, out, line0, nl, L, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// The same solve with requests of 16 bytes per lane: one instruction moves the 64 columns of a
+// chunk for TWO lines (lanes 0-31 one line, lanes 32-63 the next), i.e. half the requests per
+// chunk.  The steady state is straight-line code without conditions on lines or columns, so the
+// compiler waits for exactly the chunk it is about to park instead of for every outstanding
+// request; it covers the chunks that are complete; the incomplete chunk at the end of a line
+// goes through the 8-byte path.  kTdpAheadF / kTdpAheadB chunks are requested ahead in the two
+// passes; measured, 1 to 3 make no difference (both passes then run at the rate at which the
+// memory system serves this access pattern, about 5 TB/s over all workgroups), so it is 1.
+// Needs an even line length and 16-byte aligned arrays.  Tiles, recurrences and their order are
+// those of k_tdp_apply.
+// ---------------------------------------------------------------------------
+constexpr int kTdpAheadF = 1;
+constexpr int kTdpAheadB = 1;
+
+// A workgroup with fewer than LPW lines treats its last line as the missing ones too: their
+// lanes load, walk and store that line again (same values to the same addresses), which
+// keeps the instruction stream free of conditions.
+template <int LPW>
+__device__ __forceinline__ void tdp2_fetch(d2 (&r)[LPW / 2], const double *a, int64_t line0, int nl, int64_t L,
+                                           int64_t col0, int lane) {
+  const double *p0 = a + line0 * L + col0 + 2 * (lane & 31);
+  const int h = lane >> 5;
+#pragma unroll
+  for (int p = 0; p < LPW / 2; p++) {
+    const int line = 2 * p + h < nl ? 2 * p + h : nl - 1;
+    r[p] = *reinterpret_cast<const d2 *>(p0 + line * L);
+  }
+}
+
+template <int LPW>
+__device__ __forceinline__ void tdp2_park(TdpTile<LPW> &t, const d2 (&r)[LPW / 2], int lane) {
+  const int h = lane >> 5, j = 2 * (lane & 31);
+#pragma unroll
+  for (int p = 0; p < LPW / 2; p++) *reinterpret_cast<d2 *>(&t.v[2 * p + h][j]) = r[p];
+}
+
+template <int LPW>
+__device__ __forceinline__ void tdp2_flush(const TdpTile<LPW> &t, double *a, int64_t line0, int nl, int64_t L,
+                                           int64_t col0, int lane) {
+  const int h = lane >> 5, j = 2 * (lane & 31);
+  double *p0 = a + line0 * L + col0 + j;
+#pragma unroll
+  for (int p = 0; p < LPW / 2; p++) {
+    const int line = 2 * p + h < nl ? 2 * p + h : nl - 1;
+    *reinterpret_cast<d2 *>(p0 + line * L) = *reinterpret_cast<const d2 *>(&t.v[2 * p + h][j]);
+  }
+}
+
+// compact walks for the few chunks outside the steady state
+template <int LPW>
+__device__ __forceinline__ double tdp_walk_forward_small(TdpTile<LPW> &ts, const TdpTile<LPW> &ta,
+                                                      const TdpTile<LPW> &td, int lane, int cw, double prev) {
+#pragma unroll 1
+  for (int j = 0; j < cw; j++) {
+    prev = (ts.v[lane][j] - prev * ta.v[lane][j]) / td.v[lane][j];
+    ts.v[lane][j] = prev;
+  }
+  return prev;
+}
+
+template <int LPW>
+__device__ __forceinline__ double tdp_walk_backward_small(TdpTile<LPW> &ts, const TdpTile<LPW> &ta, int lane,
+                                                       int jtop, double prev) {
+#pragma unroll 1
+  for (int j = jtop; j >= 0; j--) {
+    prev = ts.v[lane][j] - prev * ta.v[lane][j];
+    ts.v[lane][j] = prev;
+  }
+  return prev;
+}
+
+template <int LPW, int DF = kTdpAheadF, int DB = kTdpAheadB>
+__global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__ lo,
+                                                       const double *__restrict__ dd,
+                                                       const double *__restrict__ ud, const double *sol,
+                                                       double *out, int64_t nlines, int64_t L,
+                                                       const int *__restrict__ stop) {
+  if (stopped(stop)) return;
+  static_assert(LPW % 2 == 0, "two lines per request");
+  constexpr int H = LPW / 2, C = kTdpC;
+  __shared__ TdpTile<LPW> ts[2], ta, td;
+  const int lane = threadIdx.x;
+  const int64_t line0 = (int64_t)blockIdx.x * LPW;
+  const int nl = (int)((nlines - line0) < LPW ? (nlines - line0) : LPW);
+  const int64_t nfull = L / C;  // chunks whose 64 columns all exist
+  const int tail = (int)(L - nfull * C);  // columns of the incomplete chunk behind them
+  if (nfull < 8) {
+    tdp_apply_lines<LPW>(ts, ta, td, lo, dd, ud, sol, out, line0, nl, L, lane);
+    return;
+  }
+  const bool walker = lane < LPW;
+  double prev = 0.0;
+  int tp = 0;  // tile of the chunk in hand
+  {
+    constexpr int D = DF;
+    d2 rs[D][H], ra[D][H], rd[D][H];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      tdp2_fetch<LPW>(rs[k], sol, line0, nl, L, (int64_t)k * C, lane);
+      tdp2_fetch<LPW>(ra[k], lo, line0, nl, L, (int64_t)k * C, lane);
+      tdp2_fetch<LPW>(rd[k], dd, line0, nl, L, (int64_t)k * C, lane);
+    }
+    if ((lane & 31) == 0) {
+      // column 0 has no predecessor: y_0 = (s_0 - (+0)(+0)) / d_0 = s_0 / d_0 exactly
+#pragma unroll
+      for (int p = 0; p < H; p++) ra[0][p].x = 0.0;
+    }
+    // chunk 0: nothing to flush yet
+    tdp2_park<LPW>(ts[0], rs[0], lane);
+    tdp2_park<LPW>(ta, ra[0], lane);
+    tdp2_park<LPW>(td, rd[0], lane);
+    __syncthreads();
+    tdp2_fetch<LPW>(rs[0], sol, line0, nl, L, (int64_t)D * C, lane);
+    tdp2_fetch<LPW>(ra[0], lo, line0, nl, L, (int64_t)D * C, lane);
+    tdp2_fetch<LPW>(rd[0], dd, line0, nl, L, (int64_t)D * C, lane);
+    if (walker) prev = tdp_walk_forward<LPW>(ts[0], ta, td, lane, C, prev);
+    __syncthreads();
+    int64_t c = 1;
+    for (; c + D <= nfull; c += D) {
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        const int set = (1 + k) % D;
+        const int64_t cc = c + k;
+        const int64_t cf = (cc + D < nfull ? cc + D : nfull - 1) * C;  // past the end: a chunk nobody uses
+        TdpTile<LPW> &cur = ts[cc & 1];
+        tdp2_park<LPW>(cur, rs[set], lane);
+        tdp2_park<LPW>(ta, ra[set], lane);
+        tdp2_park<LPW>(td, rd[set], lane);
+        __syncthreads();
+        tdp2_flush<LPW>(ts[(cc - 1) & 1], out, line0, nl, L, (cc - 1) * C, lane);
+        tdp2_fetch<LPW>(rs[set], sol, line0, nl, L, cf, lane);
+        tdp2_fetch<LPW>(ra[set], lo, line0, nl, L, cf, lane);
+        tdp2_fetch<LPW>(rd[set], dd, line0, nl, L, cf, lane);
+        if (walker) prev = tdp_walk_forward<LPW>(cur, ta, td, lane, C, prev);
+        __syncthreads();
+      }
+    }
+    // fewer than D complete chunks are left
+#pragma unroll
+    for (int k = 0; k < D - 1; k++) {
+      const int set = (1 + k) % D;
+      const int64_t cc = c + k;
+      if (cc < nfull) {
+        TdpTile<LPW> &cur = ts[cc & 1];
+        tdp2_park<LPW>(cur, rs[set], lane);
+        tdp2_park<LPW>(ta, ra[set], lane);
+        tdp2_park<LPW>(td, rd[set], lane);
+        __syncthreads();
+        tdp2_flush<LPW>(ts[(cc - 1) & 1], out, line0, nl, L, (cc - 1) * C, lane);
+        if (walker) prev = tdp_walk_forward_small<LPW>(cur, ta, td, lane, C, prev);
+        __syncthreads();
+      }
+    }
+    tp = (int)((nfull - 1) & 1);
+    tdp2_flush<LPW>(ts[tp], out, line0, nl, L, (nfull - 1) * C, lane);
+  }
+  // Back substitution.  Element L-1 keeps its forward value (= prev).  Every element of out is
+  // re-read by the lane that stored it.  The complete chunks are requested first, kTdpAheadB of
+  // them, then the incomplete chunk is dealt with through the 8-byte path.
+  {
+    constexpr int D = DB;
+    d2 rs[D][H], ra[D][H];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      tdp2_fetch<LPW>(rs[k], out, line0, nl, L, (nfull - 1 - k) * C, lane);
+      tdp2_fetch<LPW>(ra[k], ud, line0, nl, L, (nfull - 1 - k) * C, lane);
+    }
+    if (tail > 0) {
+      double r8s[LPW], r8a[LPW], r8d[LPW];
+      const int64_t col = nfull * C + lane;
+      tdp_fetch<LPW>(r8s, sol, line0, nl, L, col, 0.0);
+      tdp_fetch<LPW>(r8a, lo, line0, nl, L, col, 0.0);
+      tdp_fetch<LPW>(r8d, dd, line0, nl, L, col, 1.0);
+      tp ^= 1;
+      tdp_park<LPW>(ts[tp], r8s, lane);
+      tdp_park<LPW>(ta, r8a, lane);
+      tdp_park<LPW>(td, r8d, lane);
+      __syncthreads();
+      tdp_fetch<LPW>(r8a, ud, line0, nl, L, col, 0.0);
+      if (walker) prev = tdp_walk_forward_small<LPW>(ts[tp], ta, td, lane, tail, prev);
+      __syncthreads();
+      tdp_park<LPW>(ta, r8a, lane);
+      __syncthreads();
+      if (walker) prev = tdp_walk_backward_small<LPW>(ts[tp], ta, lane, tail - 2, prev);
+      __syncthreads();
+    }
+    // step 0 (chunk nfull-1): flushes the incomplete chunk, if there is one
+    {
+      const int prev_tile = tp;
+      tp ^= 1;
+      tdp2_park<LPW>(ts[tp], rs[0], lane);
+      tdp2_park<LPW>(ta, ra[0], lane);
+      __syncthreads();
+      if (tail > 0) tdp_flush<LPW>(ts[prev_tile], out, line0, nl, L, nfull * C + lane, lane);
+      tdp2_fetch<LPW>(rs[0], out, line0, nl, L, (nfull - 1 - D) * C, lane);
+      tdp2_fetch<LPW>(ra[0], ud, line0, nl, L, (nfull - 1 - D) * C, lane);
+      if (walker) prev = tdp_walk_backward_small<LPW>(ts[tp], ta, lane, tail > 0 ? C - 1 : C - 2, prev);
+      __syncthreads();
+    }
+    int64_t s1 = 1;
+    for (; s1 + D <= nfull; s1 += D) {
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        const int set = (1 + k) % D;
+        const int64_t cc = nfull - 1 - (s1 + k);
+        const int64_t cf = (cc - D > 0 ? cc - D : 0) * C;  // before the start: a chunk nobody uses
+        const int prev_tile = tp;
+        tp ^= 1;
+        TdpTile<LPW> &cur = ts[tp];
+        tdp2_park<LPW>(cur, rs[set], lane);
+        tdp2_park<LPW>(ta, ra[set], lane);
+        __syncthreads();
+        tdp2_flush<LPW>(ts[prev_tile], out, line0, nl, L, (cc + 1) * C, lane);
+        tdp2_fetch<LPW>(rs[set], out, line0, nl, L, cf, lane);
+        tdp2_fetch<LPW>(ra[set], ud, line0, nl, L, cf, lane);
+        if (walker) prev = tdp_walk_backward<LPW>(cur, ta, lane, C - 1, prev);
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < D - 1; k++) {
+      const int set = (1 + k) % D;
+      const int64_t cc = nfull - 1 - (s1 + k);
+      if (cc >= 0) {
+        const int prev_tile = tp;
+        tp ^= 1;
+        tdp2_park<LPW>(ts[tp], rs[set], lane);
+        tdp2_park<LPW>(ta, ra[set], lane);
+        __syncthreads();
+        tdp2_flush<LPW>(ts[prev_tile], out, line0, nl, L, (cc + 1) * C, lane);
+        if (walker) prev = tdp_walk_backward_small<LPW>(ts[tp], ta, lane, C - 1, prev);
+        __syncthreads();
+      }
+    }
+    tdp2_flush<LPW>(ts[tp], out, line0, nl, L, 0, lane);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_tdp_extract_csr(const int64_t *__restrict__ rowptr,
@@ -1710,6 +1956,17 @@ void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const
 
 void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const double *ud,
                       const double *sol, double *out, int64_t nlines, int64_t L) {
+  static const int pairs = [] {
+    const char *e = getenv("KRY_TDP_PAIRS");
+    return e ? atoi(e) : 1;
+  }();
+  const auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (pairs && tdp_lines_per_wave(nlines) == 16 && L % 2 == 0 && aligned16(lo) && aligned16(dd) && aligned16(ud) &&
+      aligned16(sol) && aligned16(out)) {
+    const int g = (int)((nlines + 15) / 16);
+    hipLaunchKernelGGL(k_tdp_apply2<16>, dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L, t_stop);
+    return;
+  }
   switch (tdp_lines_per_wave(nlines)) {
     case 16: launch_tdp_apply_t<16>(st, lo, dd, ud, sol, out, nlines, L); break;
     case 8: launch_tdp_apply_t<8>(st, lo, dd, ud, sol, out, nlines, L); break;

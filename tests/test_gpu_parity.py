@@ -741,7 +741,11 @@ def test_full_size_properties(ctx, n, m):
 
 @pytest.mark.parametrize("cx,cy", [(38, 18), (7, 62), (5, 64), (9, 126), (6, 130), (3, 200), (1030, 70), (2100, 66),
                                    (4200, 30), (8200, 20), (8200, 70), (7, 63), (40, 131), (9, 254), (6, 258),
-                                   (5, 700), (1030, 255), (300, 1021)])
+                                   (5, 700), (1030, 255), (300, 1021),
+                                   # 16 lines per wavefront and even line lengths of 8 chunks and more: the kernel
+                                   # with 16-byte requests (complete last chunk; 2, 62 and 4 columns in it; a last
+                                   # workgroup of 11 lines), and an odd length, which stays on the 8-byte kernel
+                                   (8200, 510), (8190, 576), (8185, 700), (8200, 1090), (8200, 701)])
 def test_line_preconditioner_bit_exact(ctx, oracle, cx, cy):
     """M^-1 v for the tridiagonal of the assembled system against
     SparseTriDiagSolver::solve (include/solver.hpp:246-273) run as ONE long
