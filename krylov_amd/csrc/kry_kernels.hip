@@ -1007,6 +1007,24 @@ __device__ __forceinline__ void tdp2_flush(const TdpTile<LPW> &t, double *a, int
   }
 }
 
+// 8-byte counterparts for the incomplete chunk at the end of a line, with the same treatment
+// of missing lines (their lanes must keep walking copies of the last line, or their stores
+// in the back substitution would put other values at that line's addresses)
+template <int LPW>
+__device__ __forceinline__ void tdp_fetch_dup(double (&r)[LPW], const double *__restrict__ a, int64_t line0,
+                                              int nl, int64_t L, int64_t col, double fill) {
+#pragma unroll
+  for (int i = 0; i < LPW; i++) r[i] = col < L ? a[(line0 + (i < nl ? i : nl - 1)) * L + col] : fill;
+}
+
+template <int LPW>
+__device__ __forceinline__ void tdp_flush_dup(const TdpTile<LPW> &t, double *a, int64_t line0, int nl,
+                                              int64_t L, int64_t col, int lane) {
+#pragma unroll
+  for (int i = 0; i < LPW; i++)
+    if (col < L) a[(line0 + (i < nl ? i : nl - 1)) * L + col] = t.v[i][lane];
+}
+
 // compact walks for the few chunks outside the steady state
 template <int LPW>
 __device__ __forceinline__ double tdp_walk_forward_small(TdpTile<LPW> &ts, const TdpTile<LPW> &ta,
@@ -1129,15 +1147,15 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
     if (tail > 0) {
       double r8s[LPW], r8a[LPW], r8d[LPW];
       const int64_t col = nfull * C + lane;
-      tdp_fetch<LPW>(r8s, sol, line0, nl, L, col, 0.0);
-      tdp_fetch<LPW>(r8a, lo, line0, nl, L, col, 0.0);
-      tdp_fetch<LPW>(r8d, dd, line0, nl, L, col, 1.0);
+      tdp_fetch_dup<LPW>(r8s, sol, line0, nl, L, col, 0.0);
+      tdp_fetch_dup<LPW>(r8a, lo, line0, nl, L, col, 0.0);
+      tdp_fetch_dup<LPW>(r8d, dd, line0, nl, L, col, 1.0);
       tp ^= 1;
       tdp_park<LPW>(ts[tp], r8s, lane);
       tdp_park<LPW>(ta, r8a, lane);
       tdp_park<LPW>(td, r8d, lane);
       __syncthreads();
-      tdp_fetch<LPW>(r8a, ud, line0, nl, L, col, 0.0);
+      tdp_fetch_dup<LPW>(r8a, ud, line0, nl, L, col, 0.0);
       if (walker) prev = tdp_walk_forward_small<LPW>(ts[tp], ta, td, lane, tail, prev);
       __syncthreads();
       tdp_park<LPW>(ta, r8a, lane);
@@ -1152,7 +1170,7 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
       tdp2_park<LPW>(ts[tp], rs[0], lane);
       tdp2_park<LPW>(ta, ra[0], lane);
       __syncthreads();
-      if (tail > 0) tdp_flush<LPW>(ts[prev_tile], out, line0, nl, L, nfull * C + lane, lane);
+      if (tail > 0) tdp_flush_dup<LPW>(ts[prev_tile], out, line0, nl, L, nfull * C + lane, lane);
       tdp2_fetch<LPW>(rs[0], out, line0, nl, L, (nfull - 1 - D) * C, lane);
       tdp2_fetch<LPW>(ra[0], ud, line0, nl, L, (nfull - 1 - D) * C, lane);
       if (walker) prev = tdp_walk_backward_small<LPW>(ts[tp], ta, lane, tail > 0 ? C - 1 : C - 2, prev);

@@ -769,6 +769,27 @@ def test_line_preconditioner_bit_exact(ctx, oracle, cx, cy):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("rows,cols", [(8187, 702), (8192, 512), (8179, 578), (8180, 705)])
+def test_line_preconditioner_every_line_counts(ctx, oracle, rows, cols):
+    """The line solver on a grid operator whose lines are all different and none of which is
+    a ghost row (a step object's first and last lines are identity rows whose values no test
+    of the compacted result sees): 16 lines per wavefront, a last workgroup of 11, 16, 3 and
+    4 lines, last chunks of 62, 0, 2 and 1 columns (the odd length stays on the kernel with
+    8-byte requests).  Bit-exact against one long Thomas recurrence over all unknowns."""
+    rng = np.random.default_rng(rows + cols)
+    w, s, nn, e = (rng.uniform(-0.4, 0.4, (rows, cols)) for _ in range(4))
+    c = 3.0 + rng.uniform(0.0, 1.0, (rows, cols))
+    s[:, 0] = 0.0   # no coupling between lines, as in the reference's numbering of a mesh
+    nn[:, -1] = 0.0
+    op = host.Operator.stencil(ctx, w, s, c, nn, e)
+    g = host.GMRESSolver(ctx, rows * cols, 2, tdp=True)
+    diags = g.assemble_preconditioner(op)
+    assert np.array_equal(diags[1:, 0], s.reshape(-1)[1:]) and np.array_equal(diags[:-1, 2], nn.reshape(-1)[:-1])
+    for scale in (1.0, 1e-120):
+        v = rng.uniform(-1.0, 1.0, rows * cols) * scale
+        assert np.array_equal(g.apply_preconditioner(v), oracle.sparse_tridiag_solve(diags, v))
+
+
 def test_line_preconditioner_general_matrix_bit_exact(ctx, oracle):
     """One line of length n (a general matrix has no row structure)."""
     rng = np.random.default_rng(3)
