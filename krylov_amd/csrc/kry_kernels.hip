@@ -1652,6 +1652,246 @@ __global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt,
   }
 }
 
+// The same sweep as a pipeline.  k_af_sweep_x has one wavefront per 64 columns and every row
+// step waits for its own loads, so it runs at the memory latency times the number of rows.
+// Here a workgroup of five wavefronts owns 64 columns: wavefront 0 walks the recurrences out
+// of LDS; wavefronts 1 to 3 each keep kAfAhead blocks of kAfB rows of one input requested
+// ahead and deposit them in LDS -- in the forward elimination the two that fetch u also turn
+// it into the coefficients Dx_m1 dt and Dx_p1 dt, whose divisions would otherwise fill the
+// walker's instruction stream --; wavefront 4 stores the results of the block before, which
+// the walker leaves in place of its inputs.  One barrier per block; in step t the loaders
+// deposit block t, the walker works on block t-1 and the storer writes block t-2 (three LDS
+// slots per array).  The loaders' steady state has no conditions (rows past the end are
+// clamped, what they fetch there is never used), so their waits name exactly the block to
+// deposit.  Arithmetic and its order are those of k_af_sweep_x.
+constexpr int kAfB = 12;
+constexpr int kAfAhead = 4;
+
+struct AfRings {
+  double v[3][3][kAfB][64];  // array, slot, row of the block, column
+};
+
+// One loader wavefront of the pipeline: blocks PHASE, PHASE + NL, ... of one input (rows
+// first, first +- 1, ... of one column, clamped to [0, hi_row]), kAfAhead of its blocks
+// requested ahead, deposited in the step that bears the block's number.  XF: 0 the values
+// as they are, 1 / 2 turned into Dx_m1 dt / Dx_p1 dt (include/time_disc.hpp:509-529).
+template <bool BACKWARD, int NL, int PHASE, int XF>
+__device__ __forceinline__ void af_loader(double (&slots)[3][kAfB][64], const double *base, int64_t P, int first,
+                                          int hi_row, int steps, int lane, double kx, double dx, double dt) {
+  constexpr int B = kAfB, A = kAfAhead;
+  double reg[A][B];
+  const auto request = [&](double(&r)[B], int block) {
+#pragma unroll
+    for (int q = 0; q < B; q++) {
+      int row = BACKWARD ? first - (block * B + q) : first + (block * B + q);
+      row = row < 0 ? 0 : row;
+      row = row > hi_row ? hi_row : row;
+      r[q] = base[(int64_t)row * P];
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < A; k++) request(reg[k], PHASE + NL * k);
+  for (int t0 = 0; t0 < steps; t0 += NL * A) {
+#pragma unroll
+    for (int kk = 0; kk < NL * A; kk++) {
+      if (kk % NL == PHASE) {
+        const int t = t0 + kk;
+        double(&slot)[B][64] = slots[t % 3];
+        double(&r)[B] = reg[kk / NL];
+#pragma unroll
+        for (int q = 0; q < B; q++)
+          slot[q][lane] = XF == 1 ? (-r[q] / 2.0 - kx) / dx * dt : XF == 2 ? (r[q] / 2.0 - kx) / dx * dt : r[q];
+        request(r, t + NL * A);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(320) void k_af_sweep_x2(IeGeom g, IeBc bc, double dt, double *__restrict__ T,
+                                                      const double *__restrict__ u,
+                                                      const double *__restrict__ rhs, double *__restrict__ y,
+                                                      double *__restrict__ ud, double *__restrict__ part) {
+  __shared__ AfRings ring;
+  constexpr int B = kAfB, A = kAfAhead;
+  const int P = g.cy + 2, cx = g.cx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;  // interior column
+  const bool live = j < g.cy;
+  const int64_t col = (live ? j : g.cy - 1) + 1;  // lanes past the last column shadow it and never store
+  double m = 0.0, last_nan = -1.0;
+  double vprev = 0.0, uprev = 0.0;
+
+  // ---- forward elimination over the interior rows 1..cx: block b holds rows b B + 1 + q ----
+  {
+    const int nblk = (cx + B - 1) / B;
+    const int steps = (nblk + 2 + A - 1) / A * A;
+    if (wave == 0) {
+      const double d0 = 2.0 * g.diffusion * g.inv_rp / (g.dx * g.dx) * dt + 1.0;  // Dx_0 * dt + 1
+      // row 0: (., 1, left term), right-hand side 0
+      vprev = 0.0 / 1.0;
+      uprev = (2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0) / 1.0;
+      if (live) {
+        y[col] = vprev;
+        ud[col] = uprev;
+      }
+      for (int t = 0; t < steps; t++) {
+        const int b = t - 1;
+        if (b >= 0 && b < nblk) {
+          const int s = b % 3;
+          const int nb = cx - b * B < B ? cx - b * B : B;
+          if (nb == B) {
+            // all LDS reads of the block first, all writes last: the dependent chain in between
+            // then runs out of registers
+            double av[B], cv[B], rv[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              av[q] = ring.v[0][s][q][lane];
+              cv[q] = ring.v[1][s][q][lane];
+              rv[q] = ring.v[2][s][q][lane];
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              const double diag = d0 - uprev * av[q];
+              vprev = (rv[q] - vprev * av[q]) / diag;
+              uprev = cv[q] / diag;
+              av[q] = vprev;
+              cv[q] = uprev;
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              ring.v[0][s][q][lane] = av[q];
+              ring.v[1][s][q][lane] = cv[q];
+            }
+          } else {
+            for (int q = 0; q < nb; q++) {
+              const double a = ring.v[0][s][q][lane];
+              const double diag = d0 - uprev * a;
+              vprev = (ring.v[2][s][q][lane] - vprev * a) / diag;
+              uprev = ring.v[1][s][q][lane] / diag;
+              ring.v[0][s][q][lane] = vprev;
+              ring.v[1][s][q][lane] = uprev;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      // row cx+1: (right term, 1, .), right-hand side 0
+      {
+        const double a = 2.0 * bc.weight[KRY_SIDE_RIGHT] - 1.0;
+        const double diag = 1.0 - uprev * a;
+        vprev = (0.0 - vprev * a) / diag;
+        uprev = 0.0 / diag;
+        if (live) {
+          const int64_t k = (int64_t)(cx + 1) * P + col;
+          y[k] = vprev;
+          ud[k] = uprev;
+        }
+      }
+    } else if (wave <= 3) {
+      const double kx = g.diffusion * g.inv_rp / g.dx;
+      // u in the row before / after the one in hand, and the right-hand side of the row in hand
+      if (wave == 1) af_loader<false, 1, 0, 1>(ring.v[0], u + col, P, 0, cx + 1, steps, lane, kx, g.dx, dt);
+      else if (wave == 2) af_loader<false, 1, 0, 2>(ring.v[1], u + col, P, 2, cx + 1, steps, lane, kx, g.dx, dt);
+      else af_loader<false, 1, 0, 0>(ring.v[2], rhs + col, P, 1, cx + 1, steps, lane, kx, g.dx, dt);
+    } else {
+      for (int t = 0; t < steps; t++) {
+        const int b = t - 2;
+        if (b >= 0 && b < nblk && live) {
+          const int s = b % 3;
+          const int nb = cx - b * B < B ? cx - b * B : B;
+          for (int q = 0; q < nb; q++) {
+            const int64_t k = (int64_t)(b * B + 1 + q) * P + col;
+            y[k] = ring.v[0][s][q][lane];
+            ud[k] = ring.v[1][s][q][lane];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have left before the others read y and ud
+  }
+  __syncthreads();  // y and ud of this workgroup's columns are written
+
+  // ---- back substitution over rows cx..0: block b holds rows cx - (b B + q) ----
+  {
+    const int nrows = cx + 1;
+    const int nblk = (nrows + B - 1) / B;
+    const int steps = (nblk + 2 + A - 1) / A * A;
+    if (wave == 0) {
+      double next = vprev;  // the final value of row cx+1
+      int nan_ip = -1;      // row of the line's last NaN among the entries that count
+      for (int t = 0; t < steps; t++) {
+        const int b = t - 1;
+        if (b >= 0 && b < nblk) {
+          const int s = b % 3;
+          const int nb = nrows - b * B < B ? nrows - b * B : B;
+          // walking backwards: the first NaN met is the line's last one, and the maximum stops there
+          const auto row = [&](int q, double yq, double uq, double tq) {
+            const int ip = cx - (b * B + q);
+            const double x = yq - next * uq;
+            next = x;
+            const double a = fabs(x);
+            const bool counts = live && ip <= cx - 1 && nan_ip < 0, is_nan = a != a;
+            m = counts && !is_nan ? max_skip_nan(a, m) : m;
+            nan_ip = counts && is_nan ? ip : nan_ip;
+            return tq + x;
+          };
+          if (nb == B) {
+            double yv[B], uv[B], tv[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              yv[q] = ring.v[0][s][q][lane];
+              uv[q] = ring.v[1][s][q][lane];
+              tv[q] = ring.v[2][s][q][lane];
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++) tv[q] = row(q, yv[q], uv[q], tv[q]);
+#pragma unroll
+            for (int q = 0; q < B; q++) ring.v[2][s][q][lane] = tv[q];
+          } else {
+            for (int q = 0; q < nb; q++)
+              ring.v[2][s][q][lane] = row(q, ring.v[0][s][q][lane], ring.v[1][s][q][lane], ring.v[2][s][q][lane]);
+          }
+        }
+        __syncthreads();
+      }
+      if (nan_ip >= 0) last_nan = (double)((int64_t)j * cx + nan_ip);
+    } else if (wave <= 3) {
+      const double *src = (wave == 1 ? y : wave == 2 ? ud : T) + col;
+      af_loader<true, 1, 0, 0>(ring.v[wave - 1], src, P, cx, cx + 1, steps, lane, 0.0, 1.0, 1.0);
+    } else {
+      // T + x of the block before the walker's, rows 1..cx only (a row of T is loaded by
+      // wavefront 3 several blocks before it is stored here)
+      for (int t = 0; t < steps; t++) {
+        const int b = t - 2;
+        if (b >= 0 && b < nblk && live) {
+          const int s = b % 3;
+          const int nb = nrows - b * B < B ? nrows - b * B : B;
+          for (int q = 0; q < nb; q++) {
+            const int ip = cx - (b * B + q);
+            if (ip >= 1) T[(int64_t)ip * P + col] = ring.v[2][s][q][lane];
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (wave != 0) return;
+  // the workgroup's summary: its last NaN position, and its maximum behind that position
+  // (lanes of later lines have no NaN, or the position would be theirs)
+  double lb = last_nan;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lb = max_skip_nan(__shfl_xor(lb, off, 64), lb);
+  if (lb >= 0.0 && (int64_t)j < (int64_t)lb / g.cx) m = 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max_skip_nan(__shfl_down(m, off, 64), m);
+  if (lane == 0) {
+    part[2 * blockIdx.x] = m;
+    part[2 * blockIdx.x + 1] = lb;
+  }
+}
+
 // The fold of ImplicitEulerApproxFact::timestep (include/time_disc.hpp:478-479; same
 // std::max semantics as above) from the workgroups' summaries of k_af_sweep_x:
 // the maximum behind the last NaN position, NaN if that is the last position.
@@ -2042,7 +2282,14 @@ void launch_af_sweep_x(hipStream_t st, const IeGeom &g, const IeBc &bc, double d
                        const double *rhs, double *y, double *ud, double *part, int *nparts) {
   const int gr = (g.cy + 63) / 64;
   *nparts = gr;
-  hipLaunchKernelGGL(k_af_sweep_x, dim3(gr), dim3(64), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
+  static const int pipelined = [] {
+    const char *e = getenv("KRY_AF_PIPELINE");
+    return e ? atoi(e) : 1;
+  }();
+  if (pipelined)
+    hipLaunchKernelGGL(k_af_sweep_x2, dim3(gr), dim3(320), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
+  else
+    hipLaunchKernelGGL(k_af_sweep_x, dim3(gr), dim3(64), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
 }
 
 void launch_max_fold(hipStream_t st, const IeGeom &g, const double *delta, const double *part, int nparts,
