@@ -1654,21 +1654,34 @@ __global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt,
 
 // The same sweep as a pipeline.  k_af_sweep_x has one wavefront per 64 columns and every row
 // step waits for its own loads, so it runs at the memory latency times the number of rows.
-// Here a workgroup of five wavefronts owns 64 columns: wavefront 0 walks the recurrences out
-// of LDS; wavefronts 1 to 3 each keep kAfAhead blocks of kAfB rows of one input requested
-// ahead and deposit them in LDS -- in the forward elimination the two that fetch u also turn
-// it into the coefficients Dx_m1 dt and Dx_p1 dt, whose divisions would otherwise fill the
-// walker's instruction stream --; wavefront 4 stores the results of the block before, which
-// the walker leaves in place of its inputs.  One barrier per block; in step t the loaders
-// deposit block t, the walker works on block t-1 and the storer writes block t-2 (three LDS
-// slots per array).  The loaders' steady state has no conditions (rows past the end are
-// clamped, what they fetch there is never used), so their waits name exactly the block to
-// deposit.  Arithmetic and its order are those of k_af_sweep_x.
+// Here a workgroup of nine wavefronts owns 64 columns and passes blocks of kAfB rows through
+// LDS, one barrier per block:
+//   wavefronts 1-3, 6-8  loaders, two per input taking every other block: each keeps kAfAhead
+//                   of its blocks requested ahead and deposits block t in step t; in the
+//                   forward elimination those that fetch u turn it into the coefficients
+//                   Dx_m1 dt and Dx_p1 dt on the way;
+//   wavefront 0     walks the recurrence that carries the dependence from row to row, one
+//                   block behind the loaders: forward the pivots and the normalised upper
+//                   diagonal (diag, ud), backward the solution x and T + x;
+//   wavefront 5     one more block behind: forward the second recurrence, y, which needs
+//                   the pivots but not the other way round (the two IEEE divisions of a row
+//                   go to two wavefronts); backward the step's maximum over x;
+//   wavefront 4     stores the finished block (y and ud, or T).
+// Results replace inputs in place; four LDS slots per array.  The loaders' steady state has
+// no conditions (rows past the end are clamped, what they fetch there is never used), so
+// their waits name exactly the block to deposit.  Every role reads its block from LDS into
+// registers first and writes last, so that LDS latency is paid once per block.  Measured at
+// 8192^2: 1.24 ms against 11.8 ms of k_af_sweep_x; with one loader per input 1.40 ms (the
+// loaders' 48 requests in flight each then set the pace), so it is the memory system's rate
+// for 512-byte rows 65 KB apart that bounds it.  Arithmetic and its order are those of
+// k_af_sweep_x.
 constexpr int kAfB = 12;
 constexpr int kAfAhead = 4;
+constexpr int kAfSlots = 4;
+constexpr int kAfThreads = 576;
 
 struct AfRings {
-  double v[3][3][kAfB][64];  // array, slot, row of the block, column
+  double v[4][kAfSlots][kAfB][64];  // array, slot, row of the block, column
 };
 
 // One loader wavefront of the pipeline: blocks PHASE, PHASE + NL, ... of one input (rows
@@ -1676,7 +1689,7 @@ struct AfRings {
 // requested ahead, deposited in the step that bears the block's number.  XF: 0 the values
 // as they are, 1 / 2 turned into Dx_m1 dt / Dx_p1 dt (include/time_disc.hpp:509-529).
 template <bool BACKWARD, int NL, int PHASE, int XF>
-__device__ __forceinline__ void af_loader(double (&slots)[3][kAfB][64], const double *base, int64_t P, int first,
+__device__ __forceinline__ void af_loader(double (&slots)[kAfSlots][kAfB][64], const double *base, int64_t P, int first,
                                           int hi_row, int steps, int lane, double kx, double dx, double dt) {
   constexpr int B = kAfB, A = kAfAhead;
   double reg[A][B];
@@ -1696,7 +1709,7 @@ __device__ __forceinline__ void af_loader(double (&slots)[3][kAfB][64], const do
     for (int kk = 0; kk < NL * A; kk++) {
       if (kk % NL == PHASE) {
         const int t = t0 + kk;
-        double(&slot)[B][64] = slots[t % 3];
+        double(&slot)[B][64] = slots[t % kAfSlots];
         double(&r)[B] = reg[kk / NL];
 #pragma unroll
         for (int q = 0; q < B; q++)
@@ -1708,135 +1721,175 @@ __device__ __forceinline__ void af_loader(double (&slots)[3][kAfB][64], const do
   }
 }
 
-__global__ __launch_bounds__(320) void k_af_sweep_x2(IeGeom g, IeBc bc, double dt, double *__restrict__ T,
-                                                      const double *__restrict__ u,
-                                                      const double *__restrict__ rhs, double *__restrict__ y,
-                                                      double *__restrict__ ud, double *__restrict__ part) {
-  __shared__ AfRings ring;
-  constexpr int B = kAfB, A = kAfAhead;
+__global__ __launch_bounds__(kAfThreads) void k_af_sweep_x2(IeGeom g, IeBc bc, double dt, double *__restrict__ T,
+                                                             const double *__restrict__ u,
+                                                             const double *__restrict__ rhs,
+                                                             double *__restrict__ y, double *__restrict__ ud,
+                                                             double *__restrict__ part) {
+  extern __shared__ __align__(16) unsigned char af_lds[];
+  AfRings &ring = *reinterpret_cast<AfRings *>(af_lds);
+  constexpr int B = kAfB, A = kAfAhead, S = kAfSlots;
   const int P = g.cy + 2, cx = g.cx;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;  // interior column
   const bool live = j < g.cy;
   const int64_t col = (live ? j : g.cy - 1) + 1;  // lanes past the last column shadow it and never store
   double m = 0.0, last_nan = -1.0;
-  double vprev = 0.0, uprev = 0.0;
+  __shared__ double carry[64];  // y of row cx+1, from the wavefront that walks y to the one that walks x
 
   // ---- forward elimination over the interior rows 1..cx: block b holds rows b B + 1 + q ----
   {
     const int nblk = (cx + B - 1) / B;
-    const int steps = (nblk + 2 + A - 1) / A * A;
+    const int steps = (nblk + 3 + 2 * A - 1) / (2 * A) * (2 * A);
     if (wave == 0) {
       const double d0 = 2.0 * g.diffusion * g.inv_rp / (g.dx * g.dx) * dt + 1.0;  // Dx_0 * dt + 1
-      // row 0: (., 1, left term), right-hand side 0
-      vprev = 0.0 / 1.0;
-      uprev = (2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0) / 1.0;
-      if (live) {
-        y[col] = vprev;
-        ud[col] = uprev;
-      }
+      // row 0: (., 1, left term)
+      double uprev = (2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0) / 1.0;
+      if (live) ud[col] = uprev;
       for (int t = 0; t < steps; t++) {
         const int b = t - 1;
         if (b >= 0 && b < nblk) {
-          const int s = b % 3;
+          const int s = b % S;
           const int nb = cx - b * B < B ? cx - b * B : B;
           if (nb == B) {
             // all LDS reads of the block first, all writes last: the dependent chain in between
             // then runs out of registers
-            double av[B], cv[B], rv[B];
+            double av[B], cv[B];
 #pragma unroll
             for (int q = 0; q < B; q++) {
               av[q] = ring.v[0][s][q][lane];
               cv[q] = ring.v[1][s][q][lane];
-              rv[q] = ring.v[2][s][q][lane];
             }
 #pragma unroll
             for (int q = 0; q < B; q++) {
               const double diag = d0 - uprev * av[q];
-              vprev = (rv[q] - vprev * av[q]) / diag;
               uprev = cv[q] / diag;
-              av[q] = vprev;
+              av[q] = diag;
               cv[q] = uprev;
             }
 #pragma unroll
             for (int q = 0; q < B; q++) {
-              ring.v[0][s][q][lane] = av[q];
+              ring.v[3][s][q][lane] = av[q];
               ring.v[1][s][q][lane] = cv[q];
             }
           } else {
             for (int q = 0; q < nb; q++) {
-              const double a = ring.v[0][s][q][lane];
-              const double diag = d0 - uprev * a;
-              vprev = (ring.v[2][s][q][lane] - vprev * a) / diag;
+              const double diag = d0 - uprev * ring.v[0][s][q][lane];
               uprev = ring.v[1][s][q][lane] / diag;
-              ring.v[0][s][q][lane] = vprev;
+              ring.v[3][s][q][lane] = diag;
               ring.v[1][s][q][lane] = uprev;
             }
           }
         }
         __syncthreads();
       }
-      // row cx+1: (right term, 1, .), right-hand side 0
+      // row cx+1: (right term, 1, .): its pivot goes to the wavefront that walks y
       {
         const double a = 2.0 * bc.weight[KRY_SIDE_RIGHT] - 1.0;
         const double diag = 1.0 - uprev * a;
-        vprev = (0.0 - vprev * a) / diag;
         uprev = 0.0 / diag;
-        if (live) {
-          const int64_t k = (int64_t)(cx + 1) * P + col;
-          y[k] = vprev;
-          ud[k] = uprev;
-        }
+        carry[lane] = diag;
+        if (live) ud[(int64_t)(cx + 1) * P + col] = uprev;
       }
-    } else if (wave <= 3) {
+    } else if (wave <= 3 || wave >= 6) {
       const double kx = g.diffusion * g.inv_rp / g.dx;
       // u in the row before / after the one in hand, and the right-hand side of the row in hand
-      if (wave == 1) af_loader<false, 1, 0, 1>(ring.v[0], u + col, P, 0, cx + 1, steps, lane, kx, g.dx, dt);
-      else if (wave == 2) af_loader<false, 1, 0, 2>(ring.v[1], u + col, P, 2, cx + 1, steps, lane, kx, g.dx, dt);
-      else af_loader<false, 1, 0, 0>(ring.v[2], rhs + col, P, 1, cx + 1, steps, lane, kx, g.dx, dt);
-    } else {
+      if (wave == 1) af_loader<false, 2, 0, 1>(ring.v[0], u + col, P, 0, cx + 1, steps, lane, kx, g.dx, dt);
+      else if (wave == 2) af_loader<false, 2, 0, 2>(ring.v[1], u + col, P, 2, cx + 1, steps, lane, kx, g.dx, dt);
+      else if (wave == 3) af_loader<false, 2, 0, 0>(ring.v[2], rhs + col, P, 1, cx + 1, steps, lane, kx, g.dx, dt);
+      else if (wave == 6) af_loader<false, 2, 1, 1>(ring.v[0], u + col, P, 0, cx + 1, steps, lane, kx, g.dx, dt);
+      else if (wave == 7) af_loader<false, 2, 1, 2>(ring.v[1], u + col, P, 2, cx + 1, steps, lane, kx, g.dx, dt);
+      else af_loader<false, 2, 1, 0>(ring.v[2], rhs + col, P, 1, cx + 1, steps, lane, kx, g.dx, dt);
+    } else if (wave == 5) {
+      // row 0: right-hand side 0
+      double vprev = 0.0 / 1.0;
+      if (live) y[col] = vprev;
       for (int t = 0; t < steps; t++) {
         const int b = t - 2;
-        if (b >= 0 && b < nblk && live) {
-          const int s = b % 3;
+        if (b >= 0 && b < nblk) {
+          const int s = b % S;
           const int nb = cx - b * B < B ? cx - b * B : B;
-          for (int q = 0; q < nb; q++) {
-            const int64_t k = (int64_t)(b * B + 1 + q) * P + col;
-            y[k] = ring.v[0][s][q][lane];
-            ud[k] = ring.v[1][s][q][lane];
+          if (nb == B) {
+            double av[B], rv[B], dv[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              av[q] = ring.v[0][s][q][lane];
+              rv[q] = ring.v[2][s][q][lane];
+              dv[q] = ring.v[3][s][q][lane];
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              vprev = (rv[q] - vprev * av[q]) / dv[q];
+              rv[q] = vprev;
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++) ring.v[2][s][q][lane] = rv[q];
+          } else {
+            for (int q = 0; q < nb; q++) {
+              vprev = (ring.v[2][s][q][lane] - vprev * ring.v[0][s][q][lane]) / ring.v[3][s][q][lane];
+              ring.v[2][s][q][lane] = vprev;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      __syncthreads();  // the pivot of row cx+1 is in carry
+      {
+        const double a = 2.0 * bc.weight[KRY_SIDE_RIGHT] - 1.0;
+        vprev = (0.0 - vprev * a) / carry[lane];
+        if (live) y[(int64_t)(cx + 1) * P + col] = vprev;
+      }
+      __syncthreads();
+      carry[lane] = vprev;  // where the back substitution starts
+    } else {
+      for (int t = 0; t < steps; t++) {
+        const int b = t - 3;
+        if (b >= 0 && b < nblk && live) {
+          const int s = b % S;
+          const int nb = cx - b * B < B ? cx - b * B : B;
+          double *yk = y + (int64_t)(b * B + 1) * P + col, *uk = ud + (int64_t)(b * B + 1) * P + col;
+          if (nb == B) {
+            double yv[B], uv[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              yv[q] = ring.v[2][s][q][lane];
+              uv[q] = ring.v[1][s][q][lane];
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+              yk[(int64_t)q * P] = yv[q];
+              uk[(int64_t)q * P] = uv[q];
+            }
+          } else {
+            for (int q = 0; q < nb; q++) {
+              yk[(int64_t)q * P] = ring.v[2][s][q][lane];
+              uk[(int64_t)q * P] = ring.v[1][s][q][lane];
+            }
           }
         }
         __syncthreads();
       }
     }
+    if (wave != 5) {
+      __syncthreads();
+      __syncthreads();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have left before the others read y and ud
   }
-  __syncthreads();  // y and ud of this workgroup's columns are written
+  __syncthreads();  // y and ud of this workgroup's columns are written, carry holds y of row cx+1
 
   // ---- back substitution over rows cx..0: block b holds rows cx - (b B + q) ----
   {
     const int nrows = cx + 1;
     const int nblk = (nrows + B - 1) / B;
-    const int steps = (nblk + 2 + A - 1) / A * A;
+    const int steps = (nblk + 2 + 2 * A - 1) / (2 * A) * (2 * A);
     if (wave == 0) {
-      double next = vprev;  // the final value of row cx+1
-      int nan_ip = -1;      // row of the line's last NaN among the entries that count
+      double next = carry[lane];  // the final value of row cx+1
       for (int t = 0; t < steps; t++) {
         const int b = t - 1;
         if (b >= 0 && b < nblk) {
-          const int s = b % 3;
+          const int s = b % S;
           const int nb = nrows - b * B < B ? nrows - b * B : B;
-          // walking backwards: the first NaN met is the line's last one, and the maximum stops there
-          const auto row = [&](int q, double yq, double uq, double tq) {
-            const int ip = cx - (b * B + q);
-            const double x = yq - next * uq;
-            next = x;
-            const double a = fabs(x);
-            const bool counts = live && ip <= cx - 1 && nan_ip < 0, is_nan = a != a;
-            m = counts && !is_nan ? max_skip_nan(a, m) : m;
-            nan_ip = counts && is_nan ? ip : nan_ip;
-            return tq + x;
-          };
           if (nb == B) {
             double yv[B], uv[B], tv[B];
 #pragma unroll
@@ -1846,40 +1899,89 @@ __global__ __launch_bounds__(320) void k_af_sweep_x2(IeGeom g, IeBc bc, double d
               tv[q] = ring.v[2][s][q][lane];
             }
 #pragma unroll
-            for (int q = 0; q < B; q++) tv[q] = row(q, yv[q], uv[q], tv[q]);
+            for (int q = 0; q < B; q++) {
+              next = yv[q] - next * uv[q];
+              yv[q] = next;
+              tv[q] = tv[q] + next;
+            }
 #pragma unroll
-            for (int q = 0; q < B; q++) ring.v[2][s][q][lane] = tv[q];
+            for (int q = 0; q < B; q++) {
+              ring.v[0][s][q][lane] = yv[q];
+              ring.v[2][s][q][lane] = tv[q];
+            }
           } else {
-            for (int q = 0; q < nb; q++)
-              ring.v[2][s][q][lane] = row(q, ring.v[0][s][q][lane], ring.v[1][s][q][lane], ring.v[2][s][q][lane]);
+            for (int q = 0; q < nb; q++) {
+              next = ring.v[0][s][q][lane] - next * ring.v[1][s][q][lane];
+              ring.v[0][s][q][lane] = next;
+              ring.v[2][s][q][lane] = ring.v[2][s][q][lane] + next;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    } else if (wave <= 3 || wave >= 6) {
+      const int arr = wave <= 3 ? wave - 1 : wave - 6;
+      const double *src = (arr == 0 ? y : arr == 1 ? ud : T) + col;
+      if (wave <= 3) af_loader<true, 2, 0, 0>(ring.v[arr], src, P, cx, cx + 1, steps, lane, 0.0, 1.0, 1.0);
+      else af_loader<true, 2, 1, 0>(ring.v[arr], src, P, cx, cx + 1, steps, lane, 0.0, 1.0, 1.0);
+    } else if (wave == 5) {
+      // The step's maximum over the solution, one block behind the walker.  Walking backwards,
+      // the first NaN met is the line's last one, and the maximum stops there.
+      int nan_ip = -1;  // row of the line's last NaN among the entries that count
+      for (int t = 0; t < steps; t++) {
+        const int b = t - 2;
+        if (b >= 0 && b < nblk) {
+          const int s = b % S;
+          const int nb = nrows - b * B < B ? nrows - b * B : B;
+          const auto row = [&](int q, double x) {
+            const int ip = cx - (b * B + q);
+            const double a = fabs(x);
+            const bool counts = live && ip <= cx - 1 && nan_ip < 0, is_nan = a != a;
+            m = counts && !is_nan ? max_skip_nan(a, m) : m;
+            nan_ip = counts && is_nan ? ip : nan_ip;
+          };
+          if (nb == B) {
+            double xv[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) xv[q] = ring.v[0][s][q][lane];
+#pragma unroll
+            for (int q = 0; q < B; q++) row(q, xv[q]);
+          } else {
+            for (int q = 0; q < nb; q++) row(q, ring.v[0][s][q][lane]);
           }
         }
         __syncthreads();
       }
       if (nan_ip >= 0) last_nan = (double)((int64_t)j * cx + nan_ip);
-    } else if (wave <= 3) {
-      const double *src = (wave == 1 ? y : wave == 2 ? ud : T) + col;
-      af_loader<true, 1, 0, 0>(ring.v[wave - 1], src, P, cx, cx + 1, steps, lane, 0.0, 1.0, 1.0);
     } else {
       // T + x of the block before the walker's, rows 1..cx only (a row of T is loaded by
       // wavefront 3 several blocks before it is stored here)
       for (int t = 0; t < steps; t++) {
         const int b = t - 2;
         if (b >= 0 && b < nblk && live) {
-          const int s = b % 3;
+          const int s = b % S;
           const int nb = nrows - b * B < B ? nrows - b * B : B;
-          for (int q = 0; q < nb; q++) {
-            const int ip = cx - (b * B + q);
-            if (ip >= 1) T[(int64_t)ip * P + col] = ring.v[2][s][q][lane];
+          const int ip0 = cx - b * B;  // the block's first row; its rows run downwards
+          if (nb == B && ip0 - (B - 1) >= 1) {
+            double tv[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) tv[q] = ring.v[2][s][q][lane];
+            double *tk = T + (int64_t)ip0 * P + col;
+#pragma unroll
+            for (int q = 0; q < B; q++) tk[-(int64_t)q * P] = tv[q];
+          } else {
+            for (int q = 0; q < nb; q++)
+              if (ip0 - q >= 1) T[(int64_t)(ip0 - q) * P + col] = ring.v[2][s][q][lane];
           }
         }
         __syncthreads();
       }
     }
   }
-  if (wave != 0) return;
-  // the workgroup's summary: its last NaN position, and its maximum behind that position
-  // (lanes of later lines have no NaN, or the position would be theirs)
+  if (wave != 5) return;
+  // the workgroup's summary, by the wavefront that took the maximum: its last NaN position,
+  // and its maximum behind that position (lanes of later lines have no NaN, or the position
+  // would be theirs)
   double lb = last_nan;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) lb = max_skip_nan(__shfl_xor(lb, off, 64), lb);
@@ -2286,9 +2388,11 @@ void launch_af_sweep_x(hipStream_t st, const IeGeom &g, const IeBc &bc, double d
     const char *e = getenv("KRY_AF_PIPELINE");
     return e ? atoi(e) : 1;
   }();
-  if (pipelined)
-    hipLaunchKernelGGL(k_af_sweep_x2, dim3(gr), dim3(320), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
-  else
+  if (pipelined) {
+    static std::atomic<uint64_t> configured{0};
+    allow_lds(&k_af_sweep_x2, sizeof(AfRings), configured, "LDS size of the pipelined sweep along x");
+    hipLaunchKernelGGL(k_af_sweep_x2, dim3(gr), dim3(kAfThreads), sizeof(AfRings), st, g, bc, dt, T, u, rhs, y, ud, part);
+  } else
     hipLaunchKernelGGL(k_af_sweep_x, dim3(gr), dim3(64), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
 }
 
