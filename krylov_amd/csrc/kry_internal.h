@@ -235,7 +235,7 @@ void launch_update_max(hipStream_t st, const IeGeom &g, double *T, const double 
 // bit 1 the maximum behind the last NaN position, bit 2 the NaN case (see k_max_fold)
 void launch_max_fold(hipStream_t st, const IeGeom &g, const double *delta, const double *part, int nparts,
                      double *scal, int phases);
-// The same fold for the approximate-factorisation step from k_af_sweep_x's summaries.
+// The same fold for the approximate-factorisation step from k_af_sweep_x2's summaries.
 void launch_af_max_final(hipStream_t st, const IeGeom &g, const double *part, int nparts, double *out);
 // Approximate factorisation: y-direction line systems (coefficients and right-hand
 // side, padded layout), and the x-direction sweep with the state update.

@@ -1585,75 +1585,8 @@ __global__ __launch_bounds__(kBlock) void k_af_rows_y(IeGeom g, IeBc bc, double 
 // back substitution adds the interior part of the solution to T and takes the
 // step's maximum over the solution entries 0..cx-1 of every line, the index
 // range the reference uses (its update reads entries 1..cx).
-__global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt, double *__restrict__ T,
-                                                    const double *__restrict__ u,
-                                                    const double *__restrict__ rhs, double *__restrict__ y,
-                                                    double *__restrict__ ud, double *__restrict__ part) {
-  const int P = g.cy + 2;
-  const int j = blockIdx.x * 64 + threadIdx.x;  // interior column
-  // the step's maximum runs over the lines in the order j = 0 .. cy-1 and along each over
-  // the entries 0 .. cx-1: position j cx + ip (see k_update_max for the fold's semantics)
-  double m = 0.0, last_nan = -1.0;
-  if (j < g.cy) {
-    const int64_t col = j + 1;
-    const double kx = g.diffusion * g.inv_rp / g.dx;
-    const double d0 = 2.0 * g.diffusion * g.inv_rp / (g.dx * g.dx) * dt + 1.0;  // Dx_0 * dt + 1
-    // row 0: (., 1, left term), right-hand side 0
-    double vprev = 0.0 / 1.0;
-    double uprev = (2.0 * bc.weight[KRY_SIDE_LEFT] - 1.0) / 1.0;
-    y[col] = vprev;
-    ud[col] = uprev;
-    for (int ip = 1; ip <= g.cx + 1; ip++) {
-      const int64_t k = (int64_t)ip * P + col;
-      double a, d, c, r;
-      if (ip <= g.cx) {
-        a = (-u[k - P] / 2.0 - kx) / g.dx * dt;  // Dx_m1 * dt
-        d = d0;
-        c = (u[k + P] / 2.0 - kx) / g.dx * dt;   // Dx_p1 * dt
-        r = rhs[k];
-      } else {
-        a = 2.0 * bc.weight[KRY_SIDE_RIGHT] - 1.0;
-        d = 1.0;
-        c = 0.0;
-        r = 0.0;
-      }
-      const double diag = d - uprev * a;
-      vprev = (r - vprev * a) / diag;
-      uprev = c / diag;
-      y[k] = vprev;
-      ud[k] = uprev;
-    }
-    // vprev is the final value of row cx+1
-    double next = vprev;
-    for (int ip = g.cx; ip >= 0; ip--) {
-      const int64_t k = (int64_t)ip * P + col;
-      const double x = y[k] - next * ud[k];
-      next = x;
-      if (ip >= 1) T[k] = T[k] + x;
-      if (ip <= g.cx - 1 && last_nan < 0.0) {
-        // walking backwards: the first NaN met is the line's last one, and the maximum stops there
-        const double a = fabs(x);
-        if (a != a) last_nan = (double)((int64_t)j * g.cx + ip);
-        else m = max_skip_nan(a, m);
-      }
-    }
-  }
-  // the workgroup's summary: its last NaN position, and its maximum behind that position
-  // (lanes of later lines have no NaN, or the position would be theirs)
-  double lb = last_nan;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) lb = max_skip_nan(__shfl_xor(lb, off, 64), lb);
-  if (lb >= 0.0 && (int64_t)j < (int64_t)lb / g.cx) m = 0.0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max_skip_nan(__shfl_down(m, off, 64), m);
-  if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = m;
-    part[2 * blockIdx.x + 1] = lb;
-  }
-}
-
-// The same sweep as a pipeline.  k_af_sweep_x has one wavefront per 64 columns and every row
-// step waits for its own loads, so it runs at the memory latency times the number of rows.
+// Run as a pipeline: with one wavefront per 64 columns and every row step waiting for its own
+// loads the sweep takes the memory latency times the number of rows (11.8 ms at 8192^2).
 // Here a workgroup of nine wavefronts owns 64 columns and passes blocks of kAfB rows through
 // LDS, one barrier per block:
 //   wavefronts 1-3, 6-8  loaders, two per input taking every other block: each keeps kAfAhead
@@ -1671,10 +1604,9 @@ __global__ __launch_bounds__(64) void k_af_sweep_x(IeGeom g, IeBc bc, double dt,
 // no conditions (rows past the end are clamped, what they fetch there is never used), so
 // their waits name exactly the block to deposit.  Every role reads its block from LDS into
 // registers first and writes last, so that LDS latency is paid once per block.  Measured at
-// 8192^2: 1.24 ms against 11.8 ms of k_af_sweep_x; with one loader per input 1.40 ms (the
+// 8192^2: 1.24 ms; with one loader per input 1.40 ms (the
 // loaders' 48 requests in flight each then set the pace), so it is the memory system's rate
-// for 512-byte rows 65 KB apart that bounds it.  Arithmetic and its order are those of
-// k_af_sweep_x.
+// for 512-byte rows 65 KB apart that bounds it.
 constexpr int kAfB = 12;
 constexpr int kAfAhead = 4;
 constexpr int kAfSlots = 4;
@@ -1995,7 +1927,7 @@ __global__ __launch_bounds__(kAfThreads) void k_af_sweep_x2(IeGeom g, IeBc bc, d
 }
 
 // The fold of ImplicitEulerApproxFact::timestep (include/time_disc.hpp:478-479; same
-// std::max semantics as above) from the workgroups' summaries of k_af_sweep_x:
+// std::max semantics as above) from the workgroups' summaries of k_af_sweep_x2:
 // the maximum behind the last NaN position, NaN if that is the last position.
 __global__ __launch_bounds__(64) void k_af_max_final(IeGeom g, const double *__restrict__ part, int np,
                                                       double *__restrict__ out) {
@@ -2384,16 +2316,9 @@ void launch_af_sweep_x(hipStream_t st, const IeGeom &g, const IeBc &bc, double d
                        const double *rhs, double *y, double *ud, double *part, int *nparts) {
   const int gr = (g.cy + 63) / 64;
   *nparts = gr;
-  static const int pipelined = [] {
-    const char *e = getenv("KRY_AF_PIPELINE");
-    return e ? atoi(e) : 1;
-  }();
-  if (pipelined) {
-    static std::atomic<uint64_t> configured{0};
-    allow_lds(&k_af_sweep_x2, sizeof(AfRings), configured, "LDS size of the pipelined sweep along x");
-    hipLaunchKernelGGL(k_af_sweep_x2, dim3(gr), dim3(kAfThreads), sizeof(AfRings), st, g, bc, dt, T, u, rhs, y, ud, part);
-  } else
-    hipLaunchKernelGGL(k_af_sweep_x, dim3(gr), dim3(64), 0, st, g, bc, dt, T, u, rhs, y, ud, part);
+  static std::atomic<uint64_t> configured{0};
+  allow_lds(&k_af_sweep_x2, sizeof(AfRings), configured, "LDS size of the sweep along x");
+  hipLaunchKernelGGL(k_af_sweep_x2, dim3(gr), dim3(kAfThreads), sizeof(AfRings), st, g, bc, dt, T, u, rhs, y, ud, part);
 }
 
 void launch_max_fold(hipStream_t st, const IeGeom &g, const double *delta, const double *part, int nparts,

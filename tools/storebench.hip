@@ -26,7 +26,7 @@ __device__ __forceinline__ void store_pol(double *p, double v) {
 // BURST rows of the result are kept in registers and stored together
 // LAYOUT of the written vector: 0 the grid's own, 1 a workgroup's rows contiguous, 2 every row of a workgroup onto the same 2 KB
 // (the stores are issued, the bytes never leave the cache: separates instruction-stream cost from memory-system cost)
-template <int K, int POL, int BURST, int TILED = 0>
+template <int K, int POL, int BURST, int TILED = 0, bool RT = false>
 __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
                                              int R, double *__restrict__ out, double *__restrict__ Wr) {
   const int t = threadIdx.x;
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long 
   for (int k = 0; k < K; k++) acc[k] = 0.0;
 #pragma unroll 4
   for (int rr = rs; rr < re; rr++) {
-    const long idx = (long)rr * P + c;
+    // RT: the read vectors are stored strip by strip (a workgroup's rows contiguous: 256 elements each)
+    const long idx = RT ? ((long)strip * rows + rr) * 256 + t : (long)rr * P + c;
     double s = 0.0;
     if (ok) {
       double v[K];
@@ -134,17 +135,17 @@ void run_lat(const char *name, const double *V, long ld, int rows, int P, double
          ms * 1e3, K, (double)h[0] / h[1], (double)h[2] / h[3]);
 }
 
-template <int K, int POL, int BURST, int TILED = 0>
+template <int K, int POL, int BURST, int TILED = 0, bool RT = false>
 void run(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr) {
   const int W = 249, nstrips = (P + W - 1) / W;
   const int nb = 1024 / nstrips;
   const int R = (rows + nb - 1) / nb, nbands = (rows + R - 1) / R;
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  for (int r = 0; r < 2; r++) hipLaunchKernelGGL((strip<K, POL, BURST, TILED>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
+  for (int r = 0; r < 2; r++) hipLaunchKernelGGL((strip<K, POL, BURST, TILED, RT>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
   CHECK(hipDeviceSynchronize());
   const int reps = 5;
   CHECK(hipEventRecord(e0));
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((strip<K, POL, BURST, TILED>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((strip<K, POL, BURST, TILED, RT>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr);
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipGetLastError());
   const double bytes = 8.0 * (K + (POL > 0 ? 1 : 0)) * (double)rows * P;
@@ -195,6 +196,26 @@ int main(int argc, char **argv) {
     run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
     run<4, 2, 16>("nt -> uncached", V, ld, rows, P, out, Wu);
     run<4, 1, 16>("plain -> uncached", V, ld, rows, P, out, Wu);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "readtiled")) {  // the read vectors strip by strip as well
+    const long ldt = 34L * rows * 256;  // 33 strips of 256 stored columns
+    double *Vt, *Wt;
+    CHECK(hipMalloc((void **)&Vt, sizeof(double) * ldt * 32)); CHECK(hipMemset(Vt, 0, sizeof(double) * ldt * 32));
+    CHECK(hipMalloc((void **)&Wt, sizeof(double) * ldt)); CHECK(hipMemset(Wt, 0, sizeof(double) * ldt));
+    run<4, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<4, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<4, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<16, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<16, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 2, 1, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<32, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    run<32, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "lat")) {
