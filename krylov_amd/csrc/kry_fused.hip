@@ -45,6 +45,7 @@
 // the ends of a grid row (band s in column 0, band n in the last column) are
 // zero, m <= kFusedMaxM.
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 
@@ -70,7 +71,20 @@ struct FusedGeom {
   // band_first + (b / nstrips) * band_step.  Its partial sums go to the slot it would have in
   // a launch over all bands, so the subsets' launches fill one array between them.
   int band_first = 0, band_step = 1;
+  // Stores on a common clock: period in ticks of the device-wide 100 MHz counter (0: off).  Every wavefront
+  // stores the rows of the new vector it holds when that counter passes a multiple of the period (or its
+  // ring is full), so that the writes of all workgroups reach the memory controllers in a few dense batches
+  // instead of a steady trickle among the reads.
+  int tick = 0;
 };
+
+// The counter all compute units share (s_memrealtime), low 32 bits: only differences are used.
+__device__ __forceinline__ uint32_t common_clock() { return (uint32_t)wall_clock64(); }
+// First multiple of the period after `now`, in the counter's low 32 bits.
+__device__ __forceinline__ uint32_t first_deadline(int period) {
+  const uint64_t now = wall_clock64();
+  return (uint32_t)((now / (uint64_t)period + 1) * (uint64_t)period);
+}
 
 // Stencil row sum in ascending column order starting from +0.0, as k_spmv_stencil.
 __device__ __forceinline__ double row_sum(double cw, double cs, double cc, double cn, double ce, double xw,
@@ -279,6 +293,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   }
   issue_tail(qa, rs - 1);
   double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // operator coefficients of the previous row
+  int p0 = rs;  // first row of the new vector not stored yet (the same in every lane of a wavefront)
+  uint32_t deadline = geo.tick > 0 ? first_deadline(geo.tick) : 0u;
   // The first row's values are awaited here (vmcnt(0)): a request still in flight on entry
   // to the loop would make every wait inside it allow for that request's position in the
   // queue as well, which drains the window once per round.
@@ -341,14 +357,21 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     // The new vector is stored kStoreRows rows at a time, from the ring (a thread reads back
     // what it wrote itself): the memory side handles a few long bursts of writes among
     // the reads better than a steady trickle.
-    const int done = rr - rs + 1;  // owned rows evaluated so far
-    if (rr >= rs && rr < re && ((done & (kStoreRows - 1)) == 0 || rr == re - 1) && colowned) {
-      const int first = rr - ((done - 1) & (kStoreRows - 1));
+    bool flush = rr - p0 + 1 == kStoreRows || rr == re - 1;  // the ring is full, or the band ends
+    if (geo.tick > 0 && (int32_t)(common_clock() - deadline) >= 0) {
+      flush = true;
+      do deadline += (uint32_t)geo.tick;
+      while ((int32_t)(common_clock() - deadline) >= 0);
+    }
+    if (rr >= rs && rr < re && flush) {
+      if (colowned) {
 #pragma unroll
-      for (int j = 0; j < kStoreRows; j++) {
-        const int r = first + j;
-        if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+        for (int j = 0; j < kStoreRows; j++) {
+          const int r = p0 + j;
+          if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+        }
       }
+      p0 = rr + 1;
     }
     sring[((sl + 2) & 3) * kBlock + t] = s_ok(rr + 2) ? o.s : 0.0;  // row rr + 2 of s_NV
     __syncthreads();
@@ -515,6 +538,8 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     }
   }
   double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // half 1: operator coefficients of the previous row
+  int p0 = rs;  // half 1: first row of the new vector not stored yet (the same in every lane of a wavefront)
+  uint32_t deadline = geo.tick > 0 ? first_deadline(geo.tick) : 0u;
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
@@ -633,14 +658,21 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? uhv : 0.0);
     const int slot = (rr - rs + 1) & (kRing - 1);
     ring[slot * kBlock + t] = u;
-    const int done = rr - rs + 1;
-    if (rr >= rs && rr < re && ((done & (kStoreRows - 1)) == 0 || rr == re - 1) && colowned) {
-      const int first = rr - ((done - 1) & (kStoreRows - 1));
+    bool flush = rr - p0 + 1 == kStoreRows || rr == re - 1;
+    if (geo.tick > 0 && (int32_t)(common_clock() - deadline) >= 0) {
+      flush = true;
+      do deadline += (uint32_t)geo.tick;
+      while ((int32_t)(common_clock() - deadline) >= 0);
+    }
+    if (rr >= rs && rr < re && flush) {
+      if (colowned) {
 #pragma unroll
-      for (int j = 0; j < kStoreRows; j++) {
-        const int r = first + j;
-        if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+        for (int j = 0; j < kStoreRows; j++) {
+          const int r = p0 + j;
+          if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+        }
       }
+      p0 = rr + 1;
     }
     {
       // the operator applied to the new vector on row q = rr - 1 (its rows q - 1 and q are
@@ -809,6 +841,27 @@ int split_from() {
 // eight ranks: fewer, taller bands).  At most 1024 workgroups (the partial-sum buffers).
 // The choice depends on nv alone, not on which kernel variant a knob selects.
 constexpr int kBandOverhead = 6;
+// Period of the common store clock for step nv, in 10 ns ticks (0: stores when the ring is full only).
+// Measured per instantiation on an 8192 x 8192 grid: 20 us for the short sweeps, 41 us up to 13 earlier
+// vectors, 61 us beyond; the shortest sweeps gain nothing.  Env KRY_STORE_TICK=period[,first_nv] overrides.
+int store_tick(int nv) {
+  static std::atomic<int> period{-2}, from{0};
+  if (period.load(std::memory_order_relaxed) == -2) {
+    const char *e = getenv("KRY_STORE_TICK");
+    int p = -1, f = 0;
+    if (e) {
+      p = atoi(e);
+      if (p < 0) p = 0;
+      const char *c = strchr(e, ',');
+      if (c) f = atoi(c + 1);
+    }
+    from.store(f, std::memory_order_relaxed);
+    period.store(p, std::memory_order_relaxed);
+  }
+  const int p = period.load(std::memory_order_relaxed);
+  if (p >= 0) return nv >= from.load(std::memory_order_relaxed) ? p : 0;
+  return nv <= 3 ? 0 : (nv <= 9 ? 2048 : (nv <= 13 ? 4096 : 6144));
+}
 FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
   g.rows = rows;
@@ -832,6 +885,7 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   }
   g.R = (rows + best_nb - 1) / best_nb;
   g.nbands = (rows + g.R - 1) / g.R;
+  g.tick = store_tick(nv);
   return g;
 }
 

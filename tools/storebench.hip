@@ -135,6 +135,87 @@ void run_lat(const char *name, const double *V, long ld, int rows, int P, double
          ms * 1e3, K, (double)h[0] / h[1], (double)h[2] / h[3]);
 }
 
+
+// Stores on a common clock: the last rows of the result wait in a register ring of BURST rows and are stored when the
+// device-wide real-time counter (100 MHz) crosses a multiple of `period` (or the ring is full), so that all workgroups
+// write at the same moments and the memory controllers see their writes as a few dense batches instead of a trickle.
+template <int K, int BURST>
+__global__ __launch_bounds__(256) void strip_tick(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
+                                                  int R, double *__restrict__ out, double *__restrict__ Wr, long period,
+                                                  unsigned long long *__restrict__ stats) {
+  const int t = threadIdx.x;
+  const int strip = blockIdx.x % nstrips, band = blockIdx.x / nstrips;
+  const int c = strip * W + t;
+  const bool ok = c < P && t < W;
+  const int rs = band * R, re = rs + R < rows ? rs + R : rows;
+  double acc[K];
+  double hold[BURST];
+#pragma unroll
+  for (int k = 0; k < K; k++) acc[k] = 0.0;
+  int p0 = rs;  // first row not stored yet
+  long last = period > 0 ? (long)(wall_clock64() / period) : 0;
+  unsigned long long nflush = 0, nfull = 0;
+#pragma unroll 2
+  for (int rr = rs; rr < re; rr++) {
+    const long idx = (long)rr * P + c;
+    double s = 0.0;
+    if (ok) {
+      double v[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = __builtin_nontemporal_load(&V[k * ld + idx]);
+#pragma unroll
+      for (int k = 0; k < K; k++) { acc[k] += v[k]; s += v[k]; }
+    }
+    const int j = (rr - rs) % BURST;
+#pragma unroll
+    for (int q = 0; q < BURST; q++) if (q == j) hold[q] = s;
+    const int pending = rr - p0 + 1;
+    bool flush = pending == BURST || rr == re - 1;
+    if (period > 0) {
+      const long now = (long)(wall_clock64() / period);
+      if (now != last) { flush = true; last = now; } else if (flush) nfull++;
+    }
+    if (flush) {
+      nflush++;
+      if (ok) {
+#pragma unroll
+        for (int q = 0; q < BURST; q++) {
+          // ring slot q holds row p0 + ((q - (p0 - rs)) mod BURST)
+          const int row = p0 + (((q - (p0 - rs)) % BURST) + BURST) % BURST;
+          if (row <= rr) __builtin_nontemporal_store(hold[q], &Wr[(long)row * P + c]);
+        }
+      }
+      p0 = rr + 1;
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; k++) s += acc[k];
+  if (s == 12345.678) out[blockIdx.x] = s;
+  if (t == 0) { atomicAdd(&stats[0], nflush); atomicAdd(&stats[1], nfull); }
+}
+
+template <int K, int BURST>
+void run_tick(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr, long period) {
+  const int W = 249, nstrips = (P + W - 1) / W;
+  const int nb = 1024 / nstrips;
+  const int R = (rows + nb - 1) / nb, nbands = (rows + R - 1) / R;
+  unsigned long long *st = (unsigned long long *)(out + 32768), h[2];
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int r = 0; r < 2; r++) hipLaunchKernelGGL((strip_tick<K, BURST>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr, period, st);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemset(st, 0, 16));
+  const int reps = 5;
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((strip_tick<K, BURST>), dim3(nstrips * nbands), dim3(256), 0, 0, V, ld, rows, P, W, nstrips, R, out, Wr, period, st);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipGetLastError());
+  CHECK(hipMemcpy(h, st, 16, hipMemcpyDeviceToHost));
+  const double bytes = 8.0 * (K + 1) * (double)rows * P;
+  printf("K=%2d ring %2d  %-20s period %6ld x 10 ns %8.1f us %7.1f GB/s  (flushes per workgroup %.1f, of them ring full %.1f)\n", K, BURST, name, period,
+         ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9, (double)h[0] / reps / (nstrips * nbands), (double)h[1] / reps / (nstrips * nbands));
+}
+
 template <int K, int POL, int BURST, int TILED = 0, bool RT = false>
 void run(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr) {
   const int W = 249, nstrips = (P + W - 1) / W;
@@ -216,6 +297,18 @@ int main(int argc, char **argv) {
     run<32, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
     run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
     run<32, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "tick")) {  // stores of all workgroups on a common clock
+    run<4, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    for (long per : {0L, 2000L, 5000L, 10000L, 20000L}) run_tick<4, 32>("nt on the clock", V, ld, rows, P, out, Wr, per);
+    run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    for (long per : {0L, 5000L, 10000L, 20000L, 40000L}) run_tick<16, 32>("nt on the clock", V, ld, rows, P, out, Wr, per);
+    run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
+    for (long per : {0L, 10000L, 20000L, 40000L, 80000L}) run_tick<32, 32>("nt on the clock", V, ld, rows, P, out, Wr, per);
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "lat")) {
