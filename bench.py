@@ -236,7 +236,8 @@ def main():
                 tj = json.load(open(tfile))
                 if (tj.get("mesh") == n_side and tj.get("m") == m and tj.get("mgs_block") == K
                         and tj.get("one_sweep_from", -1) == dev.solver().get_one_sweep()
-                        and bool(tj.get("generated_bands", False)) == dev.generated_bands()):
+                        and bool(tj.get("generated_bands", False)) == dev.generated_bands()
+                        and bool(tj.get("basis_strip_major", False)) == dev.solver().basis_strip_major()):
                     traffic = tj.get("hbm_bytes_per_launch", {}).get(name)
             except Exception:
                 traffic = None
@@ -269,6 +270,7 @@ def main():
                    "mgs_block": dev.solver().get_mgs_block(),
                    "one_sweep_from": dev.solver().get_one_sweep(),
                    "generated_bands": dev.generated_bands(),
+                   "basis_strip_major": dev.solver().basis_strip_major(),
                    "parallelism": "1 GPU", "graph": bool(graph),
                    "solver_mode": ("restarted, residual-monitored, rtol %g" % args.extended) if args.extended > 0.0
                    else "reference: one fixed cycle of m steps"},

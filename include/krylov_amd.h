@@ -201,14 +201,26 @@ int kry_gmres_get_mgs_block(const kry_gmres *g);
  * deliver): the iterate and the reported iteration count are the same, one sweep
  * more has run when the solver stops.
  * first_step < 0 switches the sweeps off; values above min(m - 2, 31) are clamped.
- * Default 2 (environment override: KRY_FUSED_FROM).  The getter returns -1 when
- * the sweeps are off or unavailable for this solver. */
+ * Default 2, or 0 for the solver of a step object on one rank (environment
+ * override: KRY_FUSED_FROM).  The getter returns -1 when the sweeps are off or
+ * unavailable for this solver. */
 int kry_gmres_set_one_sweep(kry_gmres *g, int first_step);
 int kry_gmres_get_one_sweep(const kry_gmres *g);
+/* Storage of the Krylov basis, without a counterpart in the reference (its basis is a
+ * std::vector of vectors, include/solver.hpp:236).  When every step of a cycle is a
+ * one-sweep step (first_step 0) of a step object's operator with generated bands on one
+ * rank, the solver stores the basis of that solve strip by strip: the columns of the grid
+ * are cut into the strips the sweeps' workgroups walk, and a strip's rows follow each other
+ * in memory as aligned 2 KB lines (the two columns on either side of a strip are stored by
+ * both neighbours), so that a workgroup streams consecutive lines instead of one piece per
+ * 64 KB grid row.  Results are the same bits; kry_gmres_subspace_vector and the solution
+ * are returned in grid order.  Returns 1 if the basis of the last solve was stored that way,
+ * else 0.  Environment KRY_STRIP_MAJOR=0 switches it off. */
+int kry_gmres_basis_strip_major(const kry_gmres *g);
 /* Tuning knob without a counterpart in the reference: from this step of a cycle on
  * the one-sweep steps run as workgroups of 512 threads whose halves split the basis
  * vectors (two wavefronts per SIMD where the 256-thread kernel fits one); every
- * result bit is the same.  Process-wide; first_step < 0 restores the default (14;
+ * result bit is the same.  Process-wide; first_step < 0 restores the default (18;
  * env KRY_SPLIT_FROM), values below 12 mean 12, values beyond the last step: never.
  * Returns the value in effect. */
 int kry_set_one_sweep_split(int first_step);

@@ -216,6 +216,9 @@ struct kry_op {
   // interior band entries can be evaluated instead of read (operators assembled by a step object)
   BandGen gen;
   bool has_gen = false, use_gen = true;
+  // the same recipe with strip-major velocity snapshots (StripMap), for solvers whose basis is strip-major
+  BandGen gen_strips;
+  bool has_gen_strips = false;
 };
 
 struct kry_gmres {
@@ -264,6 +267,14 @@ struct kry_gmres {
   bool scaled = false;
   // row blocks: sweep the interior bands while the halo rows of the new vector travel
   bool overlap_halo = true;
+  // Strip-major basis (StripMap): solvers of a step object on one rank keep the Krylov basis of a solve
+  // strip by strip when all of its steps are one-sweep steps with generated bands, so that the sweeps'
+  // workgroups stream whole consecutive 2 KB lines.  grid_*: the grid the solver was created for (0: none);
+  // strips: the current basis is strip-major; v0: the first basis vector in grid order (the hand-over's
+  // operator kernel reads it).
+  int grid_rows = 0, grid_cols = 0;
+  bool strips_capable = false, strips = false;
+  double *v0 = nullptr;
 };
 
 struct kry_ie {
@@ -280,6 +291,7 @@ struct kry_ie {
   // them, include/time_disc.hpp:246-274), laid out like fld[]: the one-sweep kernels
   // evaluate the interior band entries from these instead of reading four bands
   double *snap[2] = {nullptr, nullptr};
+  double *snap_strips[2] = {nullptr, nullptr};  // the same, strip-major (for solvers with a strip-major basis)
   double *rhs = nullptr;
   double *bcvals = nullptr;    // device, 3 * 2 (cx+cy), whole mesh
   double *bcvals_h = nullptr;  // pinned staging
@@ -798,13 +810,16 @@ static int fused_from_max(int m) { return m - 2 < kMgsBlock - 1 ? m - 2 : kMgsBl
 
 extern "C" {
 
-static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out);
+static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out, int grid_rows = 0,
+                        int grid_cols = 0);
 
 int kry_gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, kry_gmres **out) {
   return gmres_create(ctx, n, m, flags, 0, out);
 }
 
-static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out) {
+// grid_rows x grid_cols: the grid of the step object the solver belongs to (0: a stand-alone solver)
+static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_row, kry_gmres **out, int grid_rows,
+                        int grid_cols) {
   if (!ctx || !out) return fail(KRY_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (n < 1) return fail(KRY_ERR_INVALID, "system size must be positive");
@@ -820,6 +835,16 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   g->ld = g->halo + (n + 31) / 32 * 32 + g->halo;
   g->m = m;
   g->flags = flags;
+  const bool one_sweep_possible = !(flags & KRY_GMRES_TDP) && m <= kFusedMaxM && m >= 3;
+  if (one_sweep_possible && ctx->nranks == 1 && grid_rows > 0 && (int64_t)grid_rows * grid_cols == n &&
+      !(getenv("KRY_STRIP_MAJOR") && atoi(getenv("KRY_STRIP_MAJOR")) == 0)) {
+    // room for the strip-major form of every basis vector
+    g->grid_rows = grid_rows;
+    g->grid_cols = grid_cols;
+    g->strips_capable = true;
+    const int64_t sms = (strip_major_size(grid_rows, grid_cols) + 31) / 32 * 32;
+    if (g->halo + sms + g->halo > g->ld) g->ld = g->halo + sms + g->halo;
+  }
   // Thirty-two links per sweep: 16.5 bytes per unknown and link (the limit for ever larger
   // groups is 16) and 1/32 of the reductions (all-reduces on several ranks) of the plain
   // chain.
@@ -856,9 +881,10 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
     if (st == KRY_OK) st = dev_alloc(&g->ud, g->ld);
   }
-  if (st == KRY_OK && !(flags & KRY_GMRES_TDP) &&
-      m <= kFusedMaxM && m >= 3) {
-    int from = 2;
+  if (st == KRY_OK && g->strips_capable) st = dev_alloc(&g->v0, g->ld);
+  if (st == KRY_OK && one_sweep_possible) {
+    // hand-over from the chain: after two steps, or at once where the basis can be strip-major
+    int from = g->strips_capable ? 0 : 2;
     if (const char *e = getenv("KRY_FUSED_FROM")) from = atoi(e);
     if (from > fused_from_max(m)) from = fused_from_max(m);
     st = dev_alloc(&g->fsigma, kFusedCoef);
@@ -877,12 +903,14 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   (void)hipMemsetAsync(g->V, 0, sizeof(double) * (size_t)(m + 1) * g->ld, s);
   (void)hipMemsetAsync(g->w, 0, sizeof(double) * (size_t)g->ld, s);
   (void)hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)g->ld, s);
+  if (g->v0) (void)hipMemsetAsync(g->v0, 0, sizeof(double) * (size_t)g->ld, s);
   if (g->z) (void)hipMemsetAsync(g->z, 0, sizeof(double) * (size_t)g->ld, s);
   if (g->fsigma) launch_fill(s, g->fsigma, 1.0, kFusedCoef);
   // work vectors are addressed at their first owned entry from here on
   g->w += g->halo;
   g->vars += g->halo;
   if (g->z) g->z += g->halo;
+  if (g->v0) g->v0 += g->halo;
   g->offset_applied = true;
   launch_fill(s, g->vars, kSNaN, n);  // Solver::Solver, include/solver.hpp:16-18
   st = launch_ok("kry_gmres_create");
@@ -901,7 +929,7 @@ void kry_gmres_destroy(kry_gmres *g) {
   (void)hipStreamSynchronize(g->ctx->stream);
   const int64_t off = g->offset_applied ? g->halo : 0;
   double *bufs[] = {g->V, g->H, g->w ? g->w - off : nullptr, g->z ? g->z - off : nullptr,
-                    g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
+                    g->v0 ? g->v0 - off : nullptr, g->vars ? g->vars - off : nullptr, g->parts, g->tot, g->beta, g->y, g->work, g->bbuf,
                     g->dd, g->ud, g->R, g->G, g->fparts, g->ftot, g->fcoef, g->fsigma};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
@@ -955,6 +983,8 @@ static int fused_first(const kry_gmres *g) {
 }
 
 int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fparts ? fused_first(g) : -1; }
+
+int kry_gmres_basis_strip_major(const kry_gmres *g) { return g && g->strips ? 1 : 0; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
@@ -1030,6 +1060,18 @@ static int finish_parts(kry_gmres *g, const double **part, int nq, int *np) {
   return KRY_OK;
 }
 
+// v_0 = src / sqrt(sum of part), *out = that norm.  With a strip-major basis the vector is kept in grid
+// order as well (g->v0), for the hand-over's operator kernel.
+static void store_v0(kry_gmres *g, const double *src, const double *part, int np, double *out) {
+  hipStream_t st = g->ctx->stream;
+  if (g->strips) {
+    launch_scale_from(st, src, g->v0, part, np, g->n, out);
+    launch_to_strips(st, g->v0, basis(g, 0), g->grid_rows, g->grid_cols, false);
+  } else {
+    launch_scale_from(st, src, basis(g, 0), part, np, g->n, out);
+  }
+}
+
 static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   hipStream_t st = g->ctx->stream;
   int np = 0;
@@ -1038,7 +1080,7 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
     launch_nrm2_part(st, b_dev, g->n, g->parts, &np);
     const double *pin = g->parts;
     KCHK(finish_parts(g, &pin, 1, &np));
-    launch_scale_from(st, b_dev, basis(g, 0), pin, np, g->n, g->beta);
+    store_v0(g, b_dev, pin, np, g->beta);
   }
   g->nvec = 1;
   g->scaled = false;
@@ -1114,6 +1156,7 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
 }
 
 static bool fused_usable(const kry_gmres *g, const kry_op *op);
+static bool strips_usable(const kry_gmres *g, const kry_op *op);
 static int fused_steps_async(kry_gmres *g, kry_op *op);
 
 // Restarted GMRES(m) with Givens rotations and a residual monitor on the
@@ -1126,6 +1169,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
   const int64_t n = g->n;
   double *R = g->R, *cs = R + (int64_t)(m + 1) * m, *sn = cs + m, *gv = sn + m;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
+  g->strips = strips_usable(g, op);
   HIPCHK(hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)n, st));
   g->last_iters = 0;
   g->last_cycles = 0;
@@ -1146,7 +1190,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       launch_sub_nrm2(st, b_dev, g->w, g->w, n, g->parts, &np);
       const double *pin = g->parts;
       KCHK(finish_parts(g, &pin, 1, &np));
-      launch_scale_from(st, g->w, basis(g, 0), pin, np, n, g->beta);
+      store_v0(g, g->w, pin, np, g->beta);
       g->nvec = 1;
       g->scaled = false;
       if (g->fsigma) launch_fill(st, g->fsigma, 1.0, kFusedCoef);
@@ -1181,8 +1225,12 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       launch_add(st, g->vars, g->w, n);
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
-      launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true,
-                     g->scaled ? g->fsigma : nullptr);
+      if (g->strips)
+        launch_combine_strips(st, basis(g, 0), g->ld, g->y, m, g->vars, g->grid_rows, g->grid_cols, &g->ext->iters, true,
+                              g->scaled ? g->fsigma : nullptr);
+      else
+        launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true,
+                       g->scaled ? g->fsigma : nullptr);
     }
     KCHK(launch_ok("extended solve"));
     HIPCHK(hipMemcpyAsync(g->ext_h, g->ext, sizeof(ExtState), hipMemcpyDeviceToHost, st));
@@ -1201,6 +1249,14 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
 static bool fused_usable(const kry_gmres *g, const kry_op *op) {
   return g->fused_from >= 0 && op->kind == 0 && op->wrap_free && fused_parts(op->rows, op->cols) <= kMaxParts &&
          (g->ctx->nranks == 1 || g->halo_row == op->cols);
+}
+
+// Whether a solve with this operator keeps its basis strip-major: every step of the cycle is a one-sweep
+// step (hand-over at step 0) of the grid the solver was created for, with generated bands whose
+// velocity snapshots exist strip-major.
+static bool strips_usable(const kry_gmres *g, const kry_op *op) {
+  return g->strips_capable && fused_usable(g, op) && fused_first(g) == 0 && g->ctx->nranks == 1 && op->has_gen &&
+         op->use_gen && op->has_gen_strips && op->rows == g->grid_rows && op->cols == g->grid_cols;
 }
 
 // Totals of nq quantities from the partial sums of a one-sweep kernel, summed over the ranks.
@@ -1233,9 +1289,13 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
     // the dots of A v_from against v_0..v_from and the Gram column of v_from (the
     // product itself is recomputed by the first sweep)
     ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
-    op_apply_async(op, basis(g, i0), g->w, i0 + 1, basis(g, 0), g->ld, g->fparts, &np, g->halo_row > 0);
+    if (g->strips)  // i0 = 0: v_0 in grid order
+      op_apply_async(op, g->v0, g->w, 1, g->v0, g->ld, g->fparts, &np, g->halo_row > 0);
+    else
+      op_apply_async(op, basis(g, i0), g->w, i0 + 1, basis(g, 0), g->ld, g->fparts, &np, g->halo_row > 0);
   }
   KCHK(fused_totals(g, 2 * (i0 + 1) - 1, np));
+  const StripMap smap = g->strips ? strip_map(op->rows, op->cols) : StripMap();
   for (int i = i0; i < m; i++) {
     const bool boot = i == i0;
     launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef, g->fsigma);
@@ -1252,7 +1312,7 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
           if (n == P) break;
         }
       }
-      const BandGen *gen = op->has_gen && op->use_gen ? &op->gen : nullptr;
+      const BandGen *gen = g->strips ? &op->gen_strips : (op->has_gen && op->use_gen ? &op->gen : nullptr);
       if (ranks && g->overlap_halo && fused_bands_splittable(i, op->rows, op->cols)) {
         // The neighbours' rows of the new vector travel on the second stream while the bands of
         // rows that do not touch them are swept; the first and the last band follow.
@@ -1271,12 +1331,14 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
       } else {
         if (ranks) KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
-        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks, gen);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks, gen,
+                             kSweepAll, g->strips);
       }
       KCHK(fused_totals(g, 2 * i + 4, np));
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-      launch_arnoldi_close(st, i, b, basis(g, 0), g->ld, g->fcoef, n, op->cols, 0, n, ranks, g->fparts, &np);
+      launch_arnoldi_close(st, i, b, basis(g, 0), g->ld, g->fcoef, n, op->cols, 0, n, ranks, g->fparts, &np,
+                           g->strips ? &smap : nullptr);
     }
   }
   KCHK(fused_totals(g, 1, np));
@@ -1294,6 +1356,7 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   if (g->flags & KRY_GMRES_EXTENDED) return solve_extended(g, op, b_dev, x_dev);
   hipStream_t st = g->ctx->stream;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
+  g->strips = strips_usable(g, op);
   KCHK(initial_subspace_async(g, b_dev));
   HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
   if (fused_usable(g, op)) {
@@ -1308,8 +1371,12 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
-    launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n, nullptr, false,
-                   g->scaled ? g->fsigma : nullptr);
+    if (g->strips)
+      launch_combine_strips(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->grid_rows, g->grid_cols, nullptr, false,
+                            g->scaled ? g->fsigma : nullptr);
+    else
+      launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n, nullptr, false,
+                     g->scaled ? g->fsigma : nullptr);
   }
   if ((g->flags & KRY_GMRES_TDP) && (g->flags & KRY_GMRES_FIXED_PRECOND)) {
     ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
@@ -1332,6 +1399,7 @@ int kry_gmres_initial_subspace(kry_gmres *g, const double *b_host, double *beta)
   if (!g || !b_host) return fail(KRY_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(g->ctx->device));
   KCHK(stage_rhs(g, b_host));
+  g->strips = false;  // the step-wise interface works on the chain's layout
   KCHK(initial_subspace_async(g, g->bbuf));
   double b = 0.0;
   HIPCHK(hipMemcpyAsync(&b, g->beta, sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
@@ -1411,7 +1479,11 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
   if (i < 0 || i >= g->nvec) return fail(KRY_ERR_INVALID, "subspace vector %d does not exist (%d vectors)", i, g->nvec);
   HIPCHK(hipSetDevice(g->ctx->device));
   const double *src = basis(g, i);
-  if (g->scaled) {
+  if (g->strips) {
+    launch_unscale_strips(g->ctx->stream, src, g->scaled ? g->fsigma : nullptr, i, g->w, g->grid_rows, g->grid_cols);
+    KCHK(launch_ok("kry_gmres_subspace_vector"));
+    src = g->w;
+  } else if (g->scaled) {
     // the one-sweep steps keep their vectors un-normalised: v_i = slot_i / sigma_i
     launch_unscale(g->ctx->stream, src, g->fsigma, i, g->w, g->n);
     KCHK(launch_ok("kry_gmres_subspace_vector"));
@@ -1627,7 +1699,7 @@ int kry_ie_create_slab(kry_ctx *ctx, double c1x, double c1y, double c2x, double 
     op->wrap_free = true;  // k_offdiag / k_assemble leave the ghost columns' outward couplings at zero
     op->slab = !ie->whole();
     ie->op = op;
-    if (m > 0) st = gmres_create(ctx, ie->nloc, m, flags, P, &ie->solver);
+    if (m > 0) st = gmres_create(ctx, ie->nloc, m, flags, P, &ie->solver, ie->g.rows, P);
   }
   if (st != KRY_OK) {
     kry_ie_destroy(ie);
@@ -1657,6 +1729,7 @@ void kry_ie_destroy(kry_ie *ie) {
   for (int b = 0; b < 5; b++) (void)hipFree(ie->band[b]);
   for (int f = 0; f < 2; f++)
     if (ie->snap[f]) (void)hipFree(ie->snap[f] - ie->halo);
+  for (int f = 0; f < 2; f++) (void)hipFree(ie->snap_strips[f]);
   (void)hipFree(ie->rhs);
   (void)hipFree(ie->bcvals);
   (void)hipFree(ie->wrap);
@@ -1841,6 +1914,18 @@ int kry_ie_init_offdiag(kry_ie *ie) {
     gen.dg_top = 2.0 * ie->bc.weight[KRY_SIDE_TOP] - 1.0;
     gen.dg_left = 2.0 * ie->bc.weight[KRY_SIDE_LEFT] - 1.0;
     ie->op->has_gen = true;
+    if (ie->solver->strips_capable) {
+      const int64_t sms = strip_major_size(ie->g.rows, P);
+      for (int f = 0; f < 2; f++) {
+        if (!ie->snap_strips[f]) KCHK(dev_alloc(&ie->snap_strips[f], sms));
+        launch_to_strips(ie->ctx->stream, ie->snap[f], ie->snap_strips[f], ie->g.rows, P, true);
+      }
+      KCHK(launch_ok("init_offdiag (strip-major snapshots)"));
+      ie->op->gen_strips = gen;
+      ie->op->gen_strips.u = ie->snap_strips[0];
+      ie->op->gen_strips.v = ie->snap_strips[1];
+      ie->op->has_gen_strips = true;
+    }
   }
   ie->pending = true;
   return KRY_OK;

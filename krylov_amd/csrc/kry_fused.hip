@@ -76,6 +76,13 @@ struct FusedGeom {
   // ring is full), so that the writes of all workgroups reach the memory controllers in a few dense batches
   // instead of a steady trickle among the reads.
   int tick = 0;
+  // Strip-major vectors (sm != 0; kernels with generated bands only): the basis vectors and the velocity
+  // snapshots are stored strip by strip.  Strip s is a block of SB = (rows + 2) x kBlock values: one grid row
+  // in front, the rows, one behind; a row holds the kBlock columns the strip's workgroup touches (lane t at
+  // position t: two columns of the strip to the left, the W owned ones, two of the strip to the right), so a
+  // workgroup reads and writes whole aligned 2 KB lines that follow each other in memory as it walks down
+  // its band.  The edge columns are stored twice (by their owner and by its neighbour).
+  int sm = 0, SB = 0;
 };
 
 // The counter all compute units share (s_memrealtime), low 32 bits: only differences are used.
@@ -225,7 +232,24 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   const int ccm = cc > 0 ? cc - 1 : 0, ccp = cc + 1 < P ? cc + 1 : P - 1;
   auto rowc = [&](int r) -> int64_t { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); };  // a grid row
   auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };     // ... or a halo row
-  auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * P + cc]; };
+  // position of this lane's column (and of its two neighbours) in a row of a basis vector or
+  // velocity snapshot, and the distance between rows
+  const bool sm = GEN && geo.sm != 0;
+  const int pitch = sm ? kBlock : P;
+  int off = cc, offm = ccm, offp = ccp, soff = cc;
+  if (sm) {
+    const int base = strip * geo.SB + kBlock;             // row 0 of this strip's block
+    const int lt = t <= wown + 3 ? t : wown + 3;          // lanes beyond the strip repeat its last position
+    off = base + lt;
+    offm = base + (lt > 0 ? lt - 1 : 0);
+    offp = base + (lt + 1 < kBlock ? lt + 1 : kBlock - 1);
+    // the outermost columns of s_NV are the only values a workgroup needs that it did not store
+    // itself one step earlier: they come from their owners' blocks
+    soff = off;
+    if (t == 0 && strip > 0) soff = base - geo.SB + geo.W;
+    if (t == wown + 3 && strip + 1 < geo.nstrips) soff = base + geo.SB + 3;
+  }
+  auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * pitch + soff]; };
   auto s_ok = [&](int r) -> bool {
     return scol && ((r >= 0 && r < rows) || (s_halo != 0 && (r == -1 || r == rows)));
   };
@@ -264,9 +288,10 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {  // what the operator coefficients of row r are made of
     const int64_t ro = rowc(r) * P;
     if (GEN) {
-      n.b[1] = gen.v[ro + ccm];
-      n.b[3] = gen.v[ro + ccp];
-      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * P + cc]);
+      const int64_t rg = rowc(r) * pitch;
+      n.b[1] = gen.v[rg + offm];
+      n.b[3] = gen.v[rg + offp];
+      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * pitch + off]);
     } else {
       n.b[0] = __builtin_nontemporal_load(&b.w[ro + cc]);
       n.b[1] = __builtin_nontemporal_load(&b.s[ro + cc]);
@@ -278,16 +303,16 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   auto issue_tail = [&](Req &n, int r) __attribute__((always_inline)) {
     // a neighbouring rank's boundary row of the new vector itself (u_halo is u_out, read only
     // outside the rows this kernel writes); without one, a request that costs nothing
-    n.uh = *(u_halo != nullptr ? &u_halo[rowh(r) * P + cc] : coef);
+    n.uh = *(u_halo != nullptr ? &u_halo[rowh(r) * pitch + off] : coef);
     n.s = __builtin_nontemporal_load(s_addr(r + 2));
   };
   if (GEN) {
-    gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * P + cc]);
-    gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * P + cc]);
+    gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * pitch + off]);
+    gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * pitch + off]);
   }
   issue_op(qa, rs - 1);
   {
-    const int64_t i0 = rowc(rs - 1) * P + cc;
+    const int64_t i0 = rowc(rs - 1) * pitch + off;
 #pragma unroll
     for (int k = 0; k < NV; k++) qa.v[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i0]);
   }
@@ -305,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   auto round = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
     const bool rowvalid = rr >= 0 && rr < rows;
     const bool active = rowvalid && ucol;
-    const int64_t idxn = rowc(rr + 1) * P + cc;
+    const int64_t idxn = rowc(rr + 1) * pitch + off;
     const int q = rr - 1;  // the row whose operator application (to the new vector) completes in this round
     const bool emit = q >= rs && colowned;
     // operator coefficients of row rr
@@ -364,11 +389,13 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       while ((int32_t)(common_clock() - deadline) >= 0);
     }
     if (rr >= rs && rr < re && flush) {
-      if (colowned) {
+      // strip-major: the workgroup stores the edge columns it evaluated as well (their owners store the same bits)
+      if (sm ? (t >= 1 && t <= wown + 2) : colowned) {
+        const int so = sm ? off : c;
 #pragma unroll
         for (int j = 0; j < kStoreRows; j++) {
           const int r = p0 + j;
-          if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+          if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * pitch + so]);
         }
       }
       p0 = rr + 1;
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 // vectors.  Per lane that is half the registers, so two wavefronts fit a SIMD where the
 // kernel above runs with one, and the arithmetic of one overlaps the waiting of the other.
 constexpr int kSplitBlock = 2 * kBlock;
-constexpr int kSplitFrom = 14;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
+constexpr int kSplitFrom = 18;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
 // rows stored together: as many as the LDS left beside the parked vectors holds
 constexpr int split_store_rows(int nv) { return nv <= 42 ? 32 : 16; }
 // Vectors per half whose parked values wait in registers instead of LDS: where registers
@@ -468,7 +495,21 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   const int ccm = cc > 0 ? cc - 1 : 0, ccp = cc + 1 < P ? cc + 1 : P - 1;
   auto rowc = [&](int r) -> int64_t { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); };
   auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };
-  auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * P + cc]; };
+  // positions within a row of a basis vector / velocity snapshot, as in k_arnoldi_fused
+  const bool sm = GEN && geo.sm != 0;
+  const int pitch = sm ? kBlock : P;
+  int off = cc, offm = ccm, offp = ccp, soff = cc;
+  if (sm) {
+    const int base = strip * geo.SB + kBlock;
+    const int lt = t <= wown + 3 ? t : wown + 3;
+    off = base + lt;
+    offm = base + (lt > 0 ? lt - 1 : 0);
+    offp = base + (lt + 1 < kBlock ? lt + 1 : kBlock - 1);
+    soff = off;
+    if (t == 0 && strip > 0) soff = base - geo.SB + geo.W;
+    if (t == wown + 3 && strip + 1 < geo.nstrips) soff = base + geo.SB + 3;
+  }
+  auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * pitch + soff]; };
   auto s_ok = [&](int r) -> bool {
     return scol && ((r >= 0 && r < rows) || (s_halo != 0 && (r == -1 || r == rows)));
   };
@@ -505,9 +546,10 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {
     const int64_t ro = rowc(r) * P;
     if (GEN) {
-      n.b[1] = gen.v[ro + ccm];
-      n.b[3] = gen.v[ro + ccp];
-      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * P + cc]);
+      const int64_t rg = rowc(r) * pitch;
+      n.b[1] = gen.v[rg + offm];
+      n.b[3] = gen.v[rg + offp];
+      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * pitch + off]);
     } else {
       n.b[0] = __builtin_nontemporal_load(&b.w[ro + cc]);
       n.b[1] = __builtin_nontemporal_load(&b.s[ro + cc]);
@@ -523,18 +565,18 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     if (NA > NB && half == 0) n.v[NA - 1] = __builtin_nontemporal_load(&Vh[(int64_t)(NA - 1) * ld + idx]);
   };
   {
-    const int64_t i0 = rowc(rs - 1) * P + cc;
+    const int64_t i0 = rowc(rs - 1) * pitch + off;
     if (half == 0) {
       if (GEN) {
-        gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * P + cc]);
-        gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * P + cc]);
+        gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * pitch + off]);
+        gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * pitch + off]);
       }
       issue_op(qa, rs - 1);
       issue_row(qa, i0);
       qa.s = __builtin_nontemporal_load(s_addr(rs + 1));
     } else {
       issue_row(qa, i0);
-      qa.uh = *(u_halo != nullptr ? &u_halo[rowh(rs - 1) * P + cc] : coef);
+      qa.uh = *(u_halo != nullptr ? &u_halo[rowh(rs - 1) * pitch + off] : coef);
     }
   }
   double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // half 1: operator coefficients of the previous row
@@ -591,7 +633,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   };
 
   auto round0 = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
-    const int64_t idxn = rowc(rr + 1) * P + cc;
+    const int64_t idxn = rowc(rr + 1) * pitch + off;
     double bc[5];
     if (GEN) {
       const double gum = gu0, gup = o.gu;
@@ -642,7 +684,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   auto round1 = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
     const bool rowvalid = rr >= 0 && rr < rows;
     const bool active = rowvalid && ucol;
-    const int64_t idxn = rowc(rr + 1) * P + cc;
+    const int64_t idxn = rowc(rr + 1) * pitch + off;
     __syncthreads();
     double u = xa[t];
     const int sl = (rr - rs + 2) & 3;
@@ -654,7 +696,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     }
     u = opaque(u - lane_value(hpack, NB) * vi);
     const double uhv = o.uh;
-    n.uh = *(u_halo != nullptr ? &u_halo[rowh(rr + 1) * P + cc] : coef);
+    n.uh = *(u_halo != nullptr ? &u_halo[rowh(rr + 1) * pitch + off] : coef);
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? uhv : 0.0);
     const int slot = (rr - rs + 1) & (kRing - 1);
     ring[slot * kBlock + t] = u;
@@ -665,11 +707,13 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
       while ((int32_t)(common_clock() - deadline) >= 0);
     }
     if (rr >= rs && rr < re && flush) {
-      if (colowned) {
+      // strip-major: the workgroup stores the edge columns it evaluated as well (their owners store the same bits)
+      if (sm ? (t >= 1 && t <= wown + 2) : colowned) {
+        const int so = sm ? off : c;
 #pragma unroll
         for (int j = 0; j < kStoreRows; j++) {
           const int r = p0 + j;
-          if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * P + c]);
+          if (r <= rr) __builtin_nontemporal_store(ring[((r - rs + 1) & (kRing - 1)) * kBlock + t], &u_out[(int64_t)r * pitch + so]);
         }
       }
       p0 = rr + 1;
@@ -737,6 +781,14 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
 // cycle; one grid row: the rows a neighbouring rank needs): s_{NV+1} and its squared
 // norm (part[workgroup]).  n: unknowns of the local vector; s_halo: entries in front of
 // unknown 0 and behind unknown n - 1 exist in memory (one grid row each).
+// Position of unknown (r, c) of a grid in a strip-major vector (see FusedGeom::sm): in the block of the
+// strip that owns column c.
+__device__ __forceinline__ int64_t strip_pos(const StripMap &m, int r, int c) {
+  const int s = c / m.W;
+  return (int64_t)s * m.SB + (int64_t)(r + 1) * kBlock + (c - s * m.W + 2);
+}
+
+// map.on: the basis vectors (V, u_in, u_out) are strip-major; the bands stay in grid order.
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double *__restrict__ V, int64_t ld,
                                                            const double *__restrict__ u_in,
@@ -744,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double 
                                                            double *__restrict__ u_out, int64_t n, int P,
                                                            int64_t k0, int64_t cnt, int s_halo,
                                                            double *__restrict__ part,
-                                                           const int *__restrict__ stop) {
+                                                           const int *__restrict__ stop, StripMap map) {
   if (stopped(stop)) return;
   __shared__ double s[kBlock / 64];
   double h[NV + 1];
@@ -754,25 +806,83 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double 
   double a = 0.0;
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < cnt; j += (int64_t)gridDim.x * kBlock) {
     const int64_t i = k0 + j;
+    const int col = (int)(i % P);
+    // e: position of the unknown in a basis vector; rp: distance to the same column one grid row on
+    const int64_t e = map.on ? strip_pos(map, (int)(i / P), col) : i;
+    const int64_t rp = map.on ? kBlock : P;
     double vk[NV > 0 ? NV : 1];
 #pragma unroll
-    for (int k = 0; k < NV; k++) vk[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i]);
-    const int col = (int)(i % P);
-    const double xc = u_in[i];
-    const double xw = (s_halo || i >= P) ? u_in[i - P] : 0.0;
-    const double xe = (s_halo || i + P < n) ? u_in[i + P] : 0.0;
-    const double xs = col > 0 ? u_in[i - 1] : 0.0;
-    const double xn = col + 1 < P ? u_in[i + 1] : 0.0;
+    for (int k = 0; k < NV; k++) vk[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + e]);
+    const double xc = u_in[e];
+    const double xw = (s_halo || i >= P) ? u_in[e - rp] : 0.0;
+    const double xe = (s_halo || i + P < n) ? u_in[e + rp] : 0.0;
+    const double xs = col > 0 ? u_in[e - 1] : 0.0;
+    const double xn = col + 1 < P ? u_in[e + 1] : 0.0;
     const double tin = row_sum(b.w[i], b.s[i], b.c[i], b.n[i], b.e[i], xw, xs, xc, xn, xe);
     double u = tin / nrm;
 #pragma unroll
     for (int k = 0; k < NV; k++) u = u - h[k] * vk[k];
     u = u - h[NV] * xc;
-    __builtin_nontemporal_store(u, &u_out[i]);
+    __builtin_nontemporal_store(u, &u_out[e]);
     a = fma(u, u, a);
   }
   const double tot = block_sum(a, s);
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// dst (strip-major, all kBlock positions of every row incl. the edge columns stored twice; zero outside the
+// grid) = src (grid order, rows x P).  src_halo: the grid rows in front of / behind src exist and are copied
+// into the blocks' first / last row; otherwise those rows are set to zero.
+__global__ __launch_bounds__(kBlock) void k_to_strips(const double *__restrict__ src, double *__restrict__ dst, int rows,
+                                                       int P, StripMap map, int src_halo) {
+  const int lt = threadIdx.x;
+  const int64_t total = (int64_t)map.nstrips * (rows + 2);
+  for (int64_t q = blockIdx.x; q < total; q += gridDim.x) {
+    const int s = (int)(q / (rows + 2)), r = (int)(q % (rows + 2)) - 1;
+    const int c = s * map.W - 2 + lt;
+    const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
+    const bool ok = c >= 0 && c < P && lt <= wown + 3 && ((r >= 0 && r < rows) || src_halo != 0);
+    __builtin_nontemporal_store(ok ? src[(int64_t)r * P + c] : 0.0, &dst[(int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt]);
+  }
+}
+
+// x (grid order) = sum_k y_k V_k of strip-major vectors; per element the operations of k_combine.  A
+// workgroup takes one row of one strip at a time (lane = position in the row), so every read is one
+// aligned 2 KB line.
+__global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restrict__ V, int64_t ld,
+                                                            const double *__restrict__ y, int m,
+                                                            double *__restrict__ x, int rows, int P,
+                                                            const int *__restrict__ count, int accumulate,
+                                                            const double *__restrict__ sigma, StripMap map) {
+  __shared__ double ys[kMaxM];
+  if (count != nullptr) {
+    const int c = *count;
+    if (c < m) m = c;
+  }
+  for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = sigma != nullptr ? y[i] / sigma[i] : y[i];
+  __syncthreads();
+  const int lt = threadIdx.x;
+  const int64_t total = (int64_t)map.nstrips * rows;
+  for (int64_t q = blockIdx.x; q < total; q += gridDim.x) {
+    const int s = (int)(q / rows), r = (int)(q % rows);
+    const int c = s * map.W - 2 + lt;
+    const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
+    if (lt < 2 || lt >= wown + 2) continue;  // the strip's own columns only
+    const int64_t e = (int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt;
+    const int64_t i = (int64_t)r * P + c;
+    double acc = accumulate ? x[i] : 0.0;
+#pragma unroll 8
+    for (int k = 0; k < m; k++) acc = acc + ys[k] * __builtin_nontemporal_load(&V[(int64_t)k * ld + e]);
+    __builtin_nontemporal_store(acc, &x[i]);
+  }
+}
+
+// dst (grid order) = src (strip-major) / sigma[k]
+__global__ __launch_bounds__(kBlock) void k_unscale_strips(const double *__restrict__ src, const double *__restrict__ sigma,
+                                                            int k, double *__restrict__ dst, int64_t n, int P, StripMap map) {
+  const double sg = sigma != nullptr ? sigma[k] : 1.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    dst[i] = src[strip_pos(map, (int)(i / P), (int)(i % P))] / sg;
 }
 
 // tot[q] = sum of part[q * np .. q * np + np): one workgroup per quantity.
@@ -830,6 +940,18 @@ int split_from() {
     g_split_from.store(v, std::memory_order_relaxed);
   }
   return v < 12 ? 12 : v;
+}
+
+// Last step served by the 512-thread kernel: with 48 earlier vectors it needs scratch memory and the
+// 256-thread kernel is faster (5.72 against 6.13 ms on an 8192 x 8192 grid).  Env KRY_SPLIT_UPTO overrides.
+int split_upto() {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) {
+    r = getenv("KRY_SPLIT_UPTO") ? atoi(getenv("KRY_SPLIT_UPTO")) : 47;
+    v.store(r, std::memory_order_relaxed);
+  }
+  return r;
 }
 
 // Strips and bands for step nv.  A band of R rows costs about kBandOverhead rows more than
@@ -900,7 +1022,7 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
   allow_lds(&k_arnoldi_fused<NV, GEN>, lds, configured, "LDS size of the one-sweep kernel");
   // (with stored bands the 512-thread kernel needs scratch from 47 earlier vectors on and is slower there)
   if constexpr (NV >= 12 && (GEN || NV <= 46)) {
-    if (NV >= split_from()) {
+    if (NV >= split_from() && NV <= split_upto()) {
       constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1 - 2 * split_park_regs(NV)) * kBlock +
                                                 (split_store_rows(NV) + 4 + 7) * kBlock + (2 * NV + 4) * 4);
       static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
@@ -926,13 +1048,14 @@ struct CloseArgs {
   int s_halo;
   double *part;
   int grid;
+  StripMap map;
 };
 
 template <int NV>
 void launch_close_t(hipStream_t st, const CloseArgs &a) {
   hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(a.grid), dim3(kBlock), 0, st, a.b, a.V, a.ld, a.V + (int64_t)NV * a.ld,
                      a.coef, const_cast<double *>(a.V) + (int64_t)(NV + 1) * a.ld, a.n, a.P, a.k0, a.cnt, a.s_halo,
-                     a.part, launch_predicate_current());
+                     a.part, launch_predicate_current(), a.map);
 }
 
 template <int NV = kFusedMaxM - 1>
@@ -979,9 +1102,46 @@ int fused_parts(int rows, int cols) {
   return most;
 }
 
+StripMap strip_map(int rows, int cols) {
+  const FusedGeom g = fused_geom(rows, cols, 0);  // strips depend on the row length alone
+  StripMap m;
+  m.on = 1;
+  m.W = g.W;
+  m.nstrips = g.nstrips;
+  m.SB = (rows + 2) * kBlock;
+  return m;
+}
+
+void launch_to_strips(hipStream_t st, const double *src, double *dst, int rows, int cols, bool src_has_halo_rows) {
+  const StripMap m = strip_map(rows, cols);
+  const int64_t total = (int64_t)m.nstrips * (rows + 2);
+  hipLaunchKernelGGL(k_to_strips, dim3((unsigned)(total < 65536 ? total : 65536)), dim3(kBlock), 0, st, src, dst, rows, cols, m,
+                     src_has_halo_rows ? 1 : 0);
+}
+
+void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
+                           int cols, const int *count, bool accumulate, const double *sigma) {
+  const StripMap map = strip_map(rows, cols);
+  const int64_t total = (int64_t)map.nstrips * rows;
+  // 1024 workgroups: four per compute unit, each walking a share of the (strip, row) pairs
+  hipLaunchKernelGGL(k_combine_strips, dim3((unsigned)(total < 1024 ? total : 1024)), dim3(kBlock), 0, st, V, ld, y, m, x, rows,
+                     cols, count, accumulate ? 1 : 0, sigma, map);
+}
+
+void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols) {
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(k_unscale_strips, dim3(grid_for(n)), dim3(kBlock), 0, st, src, sigma, k, dst, n, cols,
+                     strip_map(rows, cols));
+}
+
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
-                          const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen, int which) {
+                          const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen, int which,
+                          bool strip_major) {
   FusedGeom g = fused_geom(rows, cols, nv);
+  if (strip_major && gen != nullptr) {
+    g.sm = 1;
+    g.SB = (rows + 2) * kBlock;
+  }
   *nparts = g.nstrips * g.nbands;
   int launch_bands = g.nbands;
   if (which == kSweepInterior) {
@@ -1002,10 +1162,11 @@ void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Band
 bool fused_bands_splittable(int nv, int rows, int cols) { return fused_geom(rows, cols, nv).nbands >= 3; }
 
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
-                          int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts) {
+                          int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts,
+                          const StripMap *map) {
   int grid = grid_for(cnt);
   if (grid > 1024) grid = 1024;
-  const CloseArgs a{b, V, ld, coef, n, cols, k0, cnt, has_halo ? 1 : 0, part, grid};
+  const CloseArgs a{b, V, ld, coef, n, cols, k0, cnt, has_halo ? 1 : 0, part, grid, map ? *map : StripMap()};
   FusedTable<>::close(nv, st, a);
   *nparts = grid;
 }

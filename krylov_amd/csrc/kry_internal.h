@@ -44,6 +44,14 @@ struct BandGen {
   double dg_bottom = 0.0, dg_top = 0.0, dg_left = 0.0;
 };
 
+// Strip-major storage of a vector on a rows x cols grid: the columns are cut into nstrips strips of W
+// owned columns (the strips the one-sweep kernels' workgroups walk), and strip s is stored as a block of
+// SB = (rows + 2) x kBlock values -- a grid row in front, the rows, one behind; position t of a row holds
+// column s W - 2 + t, so the two columns next to a strip on either side are stored twice.
+struct StripMap {
+  int on = 0, W = 0, SB = 0, nstrips = 0;
+};
+
 // Device-resident state of the restarted solver with residual monitor.
 struct ExtState {
   double tol_abs;  // rtol * ||b||, fixed by the first cycle
@@ -186,14 +194,29 @@ int get_split_from();
 // are fewer than three bands).  The partial sums of an interior and an edge launch together
 // fill the array of an all-bands launch.
 enum { kSweepAll = 0, kSweepInterior = 1, kSweepEdges = 2 };
+// strip_major (with gen only): the basis vectors and gen's velocity snapshots are strip-major (StripMap).
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo,
-                          const BandGen *gen = nullptr, int which = kSweepAll);
+                          const BandGen *gen = nullptr, int which = kSweepAll, bool strip_major = false);
+// The strip-major layout of vectors on a rows x cols grid, and its size in doubles.
+StripMap strip_map(int rows, int cols);
+inline int64_t strip_major_size(int rows, int cols) {
+  const StripMap m = strip_map(rows, cols);
+  return (int64_t)m.nstrips * m.SB;
+}
+// dst (strip-major) = src (grid order; src_has_halo_rows: with a grid row in front and behind, which are copied too)
+void launch_to_strips(hipStream_t st, const double *src, double *dst, int rows, int cols, bool src_has_halo_rows);
+// launch_combine / launch_unscale for strip-major basis vectors; x and dst are in grid order
+void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
+                           int cols, const int *count, bool accumulate, const double *sigma);
+void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols);
 bool fused_bands_splittable(int nv, int rows, int cols);
 // The update alone on the cnt unknowns from k0 on (n: unknowns of the local vector):
 // the new vector in slot nv + 1 and its squared norm in part.
+// map != nullptr: the basis vectors are strip-major.
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
-                          int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts);
+                          int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts,
+                          const StripMap *map = nullptr);
 // tot[q] = sum_i part[q * np + i], one workgroup per quantity
 void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot);
 // Coefficients of step i from the totals of the previous sweep (boot: of the operator

@@ -206,6 +206,10 @@ class GMRESSolver:
     def get_one_sweep(self):
         return capi.lib().kry_gmres_get_one_sweep(self.h)
 
+    def basis_strip_major(self):
+        """Whether the basis of the last solve was stored strip by strip."""
+        return bool(capi.lib().kry_gmres_basis_strip_major(self.h))
+
     def cycle_bytes(self, op):
         b = (C.c_double * capi.K_COUNT)()
         l = (C.c_int * capi.K_COUNT)()

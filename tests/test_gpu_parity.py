@@ -452,6 +452,56 @@ def test_split_sweep_kernel_bit_identical(ctx, name, shape, m):
         L.kry_set_one_sweep_split(-1)
 
 
+@pytest.mark.parametrize("name,shape,m", [("s_iso", (300, 260), 50), ("s_iso", (40, 30), 35), ("s_iso", (5, 700), 50),
+                                          ("prob1", None, 10), ("s_iso", (700, 250), 24), ("s_iso", (33, 253), 14),
+                                          ("s_iso", (64, 1030), 41), ("s_iso", (2, 3), 3), ("s_aniso", (90, 505), 20)])
+def test_strip_major_basis_bit_identical(ctx, monkeypatch, name, shape, m):
+    """A step object's solver on one rank keeps the Krylov basis of a solve
+    strip by strip (the strips the sweeps' workgroups walk; aligned 2 KB lines
+    that follow each other in memory, edge columns stored by both neighbours).
+    It is a storage order only: three implicit steps give the same max|delta|,
+    T, Hessenberg matrix and basis vectors, bit for bit, as the same steps with
+    the basis in grid order (KRY_STRIP_MAJOR=0 at creation).  One strip,
+    several strips, a last strip narrower than the others; time-dependent
+    boundary values, so the velocity snapshots differ from the live fields."""
+    def make():
+        cfg = problems.prob1() if name == "prob1" else getattr(problems, name)(*shape)
+        bcs = dict(cfg["bcs"])
+        bcs[(problems.FIELD_U, problems.LEFT)] = (True, lambda x, y, t: 0.3 + 0.1 * t + 0.0 * y)
+        bcs[(problems.FIELD_V, problems.BOTTOM)] = (True, lambda x, y, t: 0.05 * np.sin(x) * (1.0 + t))
+        cfg["bcs"] = bcs
+        return host.ImplicitEuler(ctx, **cfg, m=m, bc_time_dependent=True, one_sweep=0)
+    runs = []
+    for strips in (True, False):
+        if not strips:
+            monkeypatch.setenv("KRY_STRIP_MAJOR", "0")
+        dev = make()
+        g = dev.solver()
+        assert g.get_one_sweep() == 0  # every step of a cycle is a one-sweep step
+        deltas = [dev.timestep(0.25) for _ in range(3)]
+        assert g.basis_strip_major() == strips
+        V = np.stack([g.subspace_vector(k) for k in range(m + 1)])
+        runs.append((deltas, dev.field(0), g.hessenberg_matrix(), V, g.prev_result()))
+    (d1, T1, H1, V1, x1), (d0, T0, H0, V0, x0) = runs
+    assert d1 == d0
+    assert np.array_equal(T1, T0, equal_nan=True)
+    assert np.array_equal(H1, H0, equal_nan=True)
+    assert np.array_equal(V1, V0, equal_nan=True)
+    assert np.array_equal(x1, x0, equal_nan=True)
+    # a later hand-over, stored bands or the step-wise interface put the basis back in grid order
+    monkeypatch.delenv("KRY_STRIP_MAJOR")
+    dev = make()
+    dev.timestep(0.25)
+    assert dev.solver().basis_strip_major()
+    dev.set_generated_bands(False)
+    dev.timestep(0.25)
+    assert not dev.solver().basis_strip_major()
+    dev.set_generated_bands(True)
+    dev.solver().set_one_sweep(min(2, m - 2))
+    dev.timestep(0.25)
+    assert not dev.solver().basis_strip_major()
+
+
 def test_one_sweep_needs_a_grid_stencil(ctx, oracle):
     """A 5-band operator that couples the last entry of one grid row with the
     first entry of the next is not a 2-D stencil: the solver keeps to the chain

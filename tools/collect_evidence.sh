@@ -20,5 +20,10 @@ timeout -k 10 60 $ROOT/tools/bin/stripbench 8194 calib > $OUT/calib_known_bytes.
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -o run -- $ROOT/tools/bin/stripbench 8194 calib > /dev/null 2> $OUT/calib_fetch.err
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -o run -- $ROOT/tools/bin/stripbench 8194 calib > /dev/null 2> $OUT/calib_write.err
 python3 $ROOT/tools/parse_pmc.py $OUT/calib_fetch $OUT/calib_write > $OUT/calib_pmc.json
+# ... and on the aligned rows of a strip-major basis (the default layout of a step object's solver on one rank)
+timeout -k 10 60 $ROOT/tools/bin/stripbench 8194 calib_strips >> $OUT/calib_known_bytes.txt
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calibs_fetch -o run -- $ROOT/tools/bin/stripbench 8194 calib_strips > /dev/null 2> $OUT/calibs_fetch.err
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/calibs_write -o run -- $ROOT/tools/bin/stripbench 8194 calib_strips > /dev/null 2> $OUT/calibs_write.err
+python3 $ROOT/tools/parse_pmc.py $OUT/calibs_fetch $OUT/calibs_write > $OUT/calib_strips_pmc.json
 find $OUT -name "*.csv" | head -20
 python3 $ROOT/tools/make_traffic.py $OUT > $OUT/traffic.json

@@ -46,9 +46,13 @@ def main():
         return f
     # counter factors for 8-byte-per-lane accesses: known bytes / counted KiB
     calib = {}
+    strips = bool(cfg.get("basis_strip_major", False))
     cal_file = os.path.join(ev, "calib_pmc.json")
     if os.path.exists(cal_file):
         cpmc = json.load(open(cal_file))
+        cs_file = os.path.join(ev, "calib_strips_pmc.json")
+        if os.path.exists(cs_file):
+            cpmc.update(json.load(open(cs_file)))
         known = {}
         for line in open(os.path.join(ev, "calib_known_bytes.txt")):
             mm = re.match(r"CALIB (strip<[^>]*>) read_bytes (\d+) write_bytes (\d+)", line)
@@ -62,10 +66,12 @@ def main():
                         entry["write_factor"] = wb / (c["WRITE_SIZE"]["mean"] * 1024.0)
                     calib[key] = entry
     f8 = w8 = None
-    if calib:
-        f8 = sum(e["fetch_factor"] for e in calib.values()) / len(calib)
+    # the calibration kernels with the basis layout of the run: template argument MODE 4 = strip-major
+    mine = {k: e for k, e in calib.items() if k.endswith(", 4>") == strips}
+    if mine:
+        f8 = sum(e["fetch_factor"] for e in mine.values()) / len(mine)
         # the sweep stores its one result vector with non-temporal 8-byte stores
-        w8 = calib.get("strip<16, 1, 256, true, 3, true, 0>", {}).get("write_factor")
+        w8 = mine.get("strip<16, 1, 256, true, 3, true, %d>" % (4 if strips else 0), {}).get("write_factor")
     for name, c in pmc.items():
         f = fam_of(name)
         if not f or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
@@ -87,7 +93,7 @@ def main():
             calls[f] = calls.get(f, 0) + int(r["Calls"])
     out = {
         "mesh": mesh, "m": m, "mgs_block": block, "one_sweep_from": cfg.get("one_sweep_from"),
-        "generated_bands": bool(cfg.get("generated_bands", False)),
+        "generated_bands": bool(cfg.get("generated_bands", False)), "basis_strip_major": strips,
         "calibration_8_byte_lanes": {"per_kernel": calib, "fetch_factor": f8, "write_factor": w8},
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over one benchmark step "
                   "(tools/collect_evidence.sh); per kernel family the dispatch-weighted mean of "

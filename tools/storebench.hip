@@ -26,7 +26,7 @@ __device__ __forceinline__ void store_pol(double *p, double v) {
 // BURST rows of the result are kept in registers and stored together
 // LAYOUT of the written vector: 0 the grid's own, 1 a workgroup's rows contiguous, 2 every row of a workgroup onto the same 2 KB
 // (the stores are issued, the bytes never leave the cache: separates instruction-stream cost from memory-system cost)
-template <int K, int POL, int BURST, int TILED = 0, bool RT = false>
+template <int K, int POL, int BURST, int TILED = 0, int RT = 0>
 __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
                                              int R, double *__restrict__ out, double *__restrict__ Wr) {
   const int t = threadIdx.x;
@@ -42,9 +42,19 @@ __global__ __launch_bounds__(256) void strip(const double *__restrict__ V, long 
 #pragma unroll 4
   for (int rr = rs; rr < re; rr++) {
     // RT: the read vectors are stored strip by strip (a workgroup's rows contiguous: 256 elements each)
-    const long idx = RT ? ((long)strip * rows + rr) * 256 + t : (long)rr * P + c;
+    // RT 2: as the sweeps would read such a layout -- 252 owned columns per strip, lanes 0, 1, 254, 255 fetch the
+    // neighbouring strips' edge columns
+    long idx = RT ? ((long)strip * rows + rr) * 256 + t : (long)rr * P + c;
+    if (RT == 2) {
+      int s2 = strip, o2 = t - 2;
+      if (t < 2 && strip > 0) { s2 = strip - 1; o2 = 250 + t; }
+      if (t < 2 && strip == 0) o2 = 0;
+      if (t >= 254 && strip + 1 < nstrips) { s2 = strip + 1; o2 = t - 254; }
+      if (t >= 254 && strip + 1 >= nstrips) o2 = 251;
+      idx = ((long)s2 * rows + rr) * 256 + o2;
+    }
     double s = 0.0;
-    if (ok) {
+    if (ok || RT == 2) {
       double v[K];
 #pragma unroll
       for (int k = 0; k < K; k++) v[k] = __builtin_nontemporal_load(&V[k * ld + idx]);
@@ -216,7 +226,7 @@ void run_tick(const char *name, const double *V, long ld, int rows, int P, doubl
          ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9, (double)h[0] / reps / (nstrips * nbands), (double)h[1] / reps / (nstrips * nbands));
 }
 
-template <int K, int POL, int BURST, int TILED = 0, bool RT = false>
+template <int K, int POL, int BURST, int TILED = 0, int RT = 0>
 void run(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr) {
   const int W = 249, nstrips = (P + W - 1) / W;
   const int nb = 1024 / nstrips;
@@ -285,18 +295,18 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc((void **)&Vt, sizeof(double) * ldt * 32)); CHECK(hipMemset(Vt, 0, sizeof(double) * ldt * 32));
     CHECK(hipMalloc((void **)&Wt, sizeof(double) * ldt)); CHECK(hipMemset(Wt, 0, sizeof(double) * ldt));
     run<4, 0, 16>("reads only", V, ld, rows, P, out, Wr);
-    run<4, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<4, 0, 16, 0, 1>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
     run<4, 2, 16>("nt", V, ld, rows, P, out, Wr);
-    run<4, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<4, 2, 16, 1, 1>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
     run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
-    run<16, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 0, 16, 0, 1>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
     run<16, 2, 16>("nt", V, ld, rows, P, out, Wr);
-    run<16, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
-    run<16, 2, 1, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 2, 16, 1, 1>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 2, 1, 1, 1>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
     run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
-    run<32, 0, 16, 0, true>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<32, 0, 16, 0, 1>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
     run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
-    run<32, 2, 16, 1, true>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
+    run<32, 2, 16, 1, 1>("nt, all strip-major", Vt, ldt, rows, P, out, Wt);
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "tick")) {  // stores of all workgroups on a common clock
@@ -309,6 +319,21 @@ int main(int argc, char **argv) {
     run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
     run<32, 2, 16>("nt", V, ld, rows, P, out, Wr);
     for (long per : {0L, 10000L, 20000L, 40000L, 80000L}) run_tick<32, 32>("nt on the clock", V, ld, rows, P, out, Wr, per);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "readhalo")) {  // strip-major reads with the edge columns taken from the neighbouring strips
+    const long ldt = 34L * rows * 256;
+    double *Vt, *Wt;
+    CHECK(hipMalloc((void **)&Vt, sizeof(double) * ldt * 32)); CHECK(hipMemset(Vt, 0, sizeof(double) * ldt * 32));
+    CHECK(hipMalloc((void **)&Wt, sizeof(double) * ldt)); CHECK(hipMemset(Wt, 0, sizeof(double) * ldt));
+    run<16, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<16, 0, 16, 0, 1>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<16, 0, 16, 0, 2>("reads only, strip-major + edges", Vt, ldt, rows, P, out, Wt);
+    run<16, 2, 16, 1, 2>("nt, strip-major + edges", Vt, ldt, rows, P, out, Wt);
+    run<32, 0, 16>("reads only", V, ld, rows, P, out, Wr);
+    run<32, 0, 16, 0, 1>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
+    run<32, 0, 16, 0, 2>("reads only, strip-major + edges", Vt, ldt, rows, P, out, Wt);
+    run<32, 2, 16, 1, 2>("nt, strip-major + edges", Vt, ldt, rows, P, out, Wt);
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "lat")) {

@@ -11,6 +11,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // VEC = 1: 8 bytes per lane, strip of BLK - 2 owned columns starting one column early (unaligned);
 // VEC = 2: 16 bytes per lane, strip of 2 * BLK columns starting at an even column.
+// MODE 4 (VEC = 1): strip-major vectors -- strip s is a block of rows x BLK values, a workgroup reads whole
+// aligned rows of BLK values and writes positions 1 .. W + 2 of them (the one-sweep kernels on a strip-major basis).
 template <int K, int VEC, int BLK, bool BARRIER, int NW = 0, bool NT = false, int MODE = 0>
 __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long ld, int rows, int P, int W, int nstrips,
                                              int R, double *__restrict__ out, double *__restrict__ Wr = nullptr) {
@@ -19,7 +21,7 @@ __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long 
   const int strip = blockIdx.x % nstrips, band = blockIdx.x / nstrips;
   const int cs = strip * W;
   const int c = VEC == 1 ? cs - 1 + t : cs + 2 * t;
-  const bool ok = c >= 0 && c + VEC <= P && (VEC == 1 ? t <= W + 1 : 2 * t < W);
+  const bool ok = MODE == 4 ? true : (c >= 0 && c + VEC <= P && (VEC == 1 ? t <= W + 1 : 2 * t < W));
   const int rs = band * R, re = rs + R < rows ? rs + R : rows;
   double acc[K];
   double held = 0.0;
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long 
   for (int k = 0; k < K; k++) acc[k] = 0.0;
 #pragma unroll 8
   for (int rr = rs; rr < re; rr++) {
-    const long idx = (long)rr * P + c;
+    const long idx = MODE == 4 ? ((long)strip * rows + rr) * BLK + t : (long)rr * P + c;
     double s = 0.0;
     if (ok) {
       if (VEC == 1) {
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(BLK) void strip(const double *__restrict__ V, long 
     }
     if (MODE == 1) s = (double)rr;
     if (MODE == 2) { const double cur = s; s = held; held = cur; }
-    if (NW > 0 && ok && MODE != 3 && (MODE != 2 || rr > rs)) {
-      const long idx = (long)(MODE == 2 ? rr - 1 : rr) * P + c;
+    if (NW > 0 && ok && MODE != 3 && (MODE != 2 || rr > rs) && (MODE != 4 || (t >= 1 && t <= W + 2))) {
+      const long idx = MODE == 4 ? ((long)strip * rows + rr) * BLK + t : (long)(MODE == 2 ? rr - 1 : rr) * P + c;
 #pragma unroll
       for (int k = 0; k < NW; k++) {
         if (VEC == 1) { if (NT) __builtin_nontemporal_store(s + k, &Wr[k * ld + idx]); else Wr[k * ld + idx] = s + k; }
@@ -126,6 +128,21 @@ int main(int argc, char **argv) {
     run<16, 1, 256, true>("8 B/lane, reads only", V, ld, rows, P, 1024, out);
     run<16, 1, 256, true, 3>("8 B/lane, 3 write streams", V, ld, rows, P, 1024, out, Wr);
     run<16, 1, 256, true, 3, true>("8 B/lane, 3 NT write streams", V, ld, rows, P, 1024, out, Wr);
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "calib_strips")) {
+    // The same for strip-major vectors (aligned rows of 256 values per strip): known bytes of the access
+    // pattern of the one-sweep kernels on a strip-major basis.
+    const int Wc = 249, nstrips = 33;
+    const long lds = (long)nstrips * rows * 256;
+    CHECK(hipFree(V)); CHECK(hipFree(Wr));
+    CHECK(hipMalloc((void **)&V, sizeof(double) * lds * 16)); CHECK(hipMemset(V, 0, sizeof(double) * lds * 16));
+    CHECK(hipMalloc((void **)&Wr, sizeof(double) * lds * 3)); CHECK(hipMemset(Wr, 0, sizeof(double) * lds * 3));
+    const double rd = 8.0 * (double)rows * nstrips * 256, wr = 8.0 * (double)rows * nstrips * (Wc + 2);
+    printf("CALIB strip<16, 1, 256, true, 0, false, 4> read_bytes %.0f write_bytes 0\n", 16 * rd);
+    printf("CALIB strip<16, 1, 256, true, 3, true, 4> read_bytes %.0f write_bytes %.0f\n", 16 * rd, 3 * wr);
+    run<16, 1, 256, true, 0, false, 4>("8 B/lane, strip-major, reads only", V, lds, rows, P, 1024, out);
+    run<16, 1, 256, true, 3, true, 4>("8 B/lane, strip-major, 3 NT write streams", V, lds, rows, P, 1024, out, Wr);
     return 0;
   }
   for (int wgs : {1024}) {
