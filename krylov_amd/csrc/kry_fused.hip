@@ -56,6 +56,11 @@ namespace kry {
 namespace {
 
 constexpr int kStripMax = kBlock - 4;  // owned columns per workgroup (two halo columns on either side)
+// From this many earlier vectors on the update s_{NV+1} = w - sum_k c_k s_k is evaluated in two groups,
+//   (w - c_0 s_0 - ... - c_{NA-1} s_{NA-1}) - (c_NA s_NA + ... + c_NV s_NV),   NA = (NV + 1) / 2,
+// by every kernel that forms the new vector (both sweeps and the closing kernel: same bits everywhere), so that
+// the two halves of a 512-thread workgroup can work on their groups at the same time.
+constexpr int kGroupedFrom = 12;
 // Rows of the new vector stored together = rows of it kept in LDS (a power of two, at least 4).
 // Longer bursts are better as long as the LDS they take does not cost a resident workgroup
 // (4 workgroups per compute unit are resident up to 5 earlier vectors, 3 up to 10, 2 up to 21
@@ -368,12 +373,24 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     const double tin = row_sum(bc[0], bc[1], bc[2], bc[3], bc[4], sring[((sl + 3) & 3) * kBlock + t], xs, vi, xn,
                                sring[((sl + 1) & 3) * kBlock + t]);
     double u = tin / nrm;
+    constexpr int NG = NV >= kGroupedFrom ? (NV + 1) / 2 : NV + 1;  // vectors subtracted one by one
+    double pg = 0.0;                                                // the second group's sum
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       n.v[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + idxn]);
-      u = u - lane_value(hpack, k) * o.v[k];
+      const double term = lane_value(hpack, k) * o.v[k];
+      if (k < NG)
+        u = u - term;
+      else
+        pg = k == NG ? term : pg + term;
     }
-    u = opaque(u - lane_value(hpack, NV) * vi);
+    if (NG <= NV) {
+      const double term = lane_value(hpack, NV) * vi;
+      pg = NG == NV ? term : pg + term;
+      u = opaque(u - pg);
+    } else {
+      u = opaque(u - lane_value(hpack, NV) * vi);
+    }
     issue_tail(n, rr + 1);
     // outside the columns and rows evaluated here: zero, or a neighbouring rank's row of the new vector
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? o.uh : 0.0);
@@ -443,6 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 // vectors.  Per lane that is half the registers, so two wavefronts fit a SIMD where the
 // kernel above runs with one, and the arithmetic of one overlaps the waiting of the other.
 constexpr int kSplitBlock = 2 * kBlock;
+constexpr int kUniformHalfUpto = 37;
 constexpr int kSplitFrom = 18;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
 // rows stored together: as many as the LDS left beside the parked vectors holds
 constexpr int split_store_rows(int nv) { return nv <= 42 ? 32 : 16; }
@@ -476,7 +494,11 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   double *bcs = xa + kBlock;                        // 5 x kBlock: operator coefficients of row rr
   double *tvs = bcs + 5 * kBlock;                   // kBlock: the operator applied to the new vector, row rr - 1
   double *red = tvs + kBlock;                       // NQ x 4
-  const int half = threadIdx.x >> 8, t = threadIdx.x & (kBlock - 1);
+  // which half: the same in every lane of a wavefront; up to kUniformHalfUpto earlier vectors it is read as
+  // such (from the first lane), so that the halves' loops, their counters, predicates and row addresses live in
+  // scalar registers (1-2 % faster; beyond, the register allocation of that variant needs scratch)
+  const int half = NV <= kUniformHalfUpto ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : (int)(threadIdx.x >> 8);
+  const int t = threadIdx.x & (kBlock - 1);
   const int lane = t & 63, wv = t >> 6;
   const int tm = t > 0 ? t - 1 : 0, tp = t + 1 < kBlock ? t + 1 : kBlock - 1;
   const int strip = blockIdx.x % geo.nstrips, band = geo.band_first + (blockIdx.x / geo.nstrips) * geo.band_step;
@@ -632,39 +654,66 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     }
   };
 
+  // Operator coefficients of grid row `row` from the velocities next to the cell (GEN):
+  // SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1, include/space_disc.hpp:83-113, as k_offdiag forms them;
+  // ghost rows as k_assemble leaves them (include/time_disc.hpp:304-337)
+  auto form_coeffs = [&](const int row, const double gum, const double gup, const double vm, const double vp,
+                         double *out) __attribute__((always_inline)) {
+    const int ip = gen.row0 + row;
+    const bool xin = ip >= 1 && ip <= gen.cx;
+    const double iw = opaque((-gum / 2.0 - gen.kx) / gen.dx);
+    const double is = opaque((-vm / 2.0 - gen.ky) / gen.dy);
+    const double in = opaque((vp / 2.0 - gen.ky) / gen.dy);
+    const double ie = opaque((gup / 2.0 - gen.kx) / gen.dx);
+    const bool inner = xin && yin;
+    out[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
+    out[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);
+    out[3] = inner ? in : ((xin && c == 0) ? 1.0 : 0.0);
+    out[4] = inner ? ie : ((yin && ip == 0) ? 1.0 : 0.0);
+    out[2] = inner ? gdiag : (xin ? (c == 0 ? gen.dg_bottom : gen.dg_top) : (yin ? gen.dg_left : 1.0));
+  };
+  // GEN, half 0: the coefficients of the row the next round works on.  They are formed one round ahead,
+  // between the round's two barriers, while half 1 continues the update chain and half 0 would only wait:
+  // their four divisions are then off the path from one row to the next.  On entry to round rr:
+  // bcn = coefficients of row rr, gu0 / gu1 = velocity of rows rr and rr + 1.
+  // (Up to 44 earlier vectors; beyond, the registers this takes cost more than it saves.)
+  constexpr bool AHEAD = GEN && NV <= 44;
+  constexpr bool W_AHEAD = false;  // also w = (A s_NV) / sigma of the next row (measured: slower, half 0 becomes the longer one)
+  // So is w = (A s_NV) / sigma on that row (wn): the rows of s_NV it needs are in the ring by then.
+  double bcn[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  double wn = 0.0;
+  auto form_w = [&](const int row, const double *cf) __attribute__((always_inline)) -> double {
+    const int sl = (row - rs + 2) & 3;
+    const double *s0 = sring + sl * kBlock;
+    const double xs = c > 0 ? s0[tm] : 0.0;
+    const double xn = c + 1 < P ? s0[tp] : 0.0;
+    const double tin = row_sum(cf[0], cf[1], cf[2], cf[3], cf[4], sring[((sl + 3) & 3) * kBlock + t], xs, s0[t], xn,
+                               sring[((sl + 1) & 3) * kBlock + t]);
+    return tin / nrm;
+  };
+  if (AHEAD && half == 0) {
+    form_coeffs(rs - 1, gu0, qa.gu, qa.b[1], qa.b[3], bcn);
+    gu0 = gu1;
+    gu1 = qa.gu;
+    if (W_AHEAD) wn = form_w(rs - 1, bcn);
+  }
+
   auto round0 = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
     const int64_t idxn = rowc(rr + 1) * pitch + off;
     double bc[5];
-    if (GEN) {
+    if (GEN && !AHEAD) {
       const double gum = gu0, gup = o.gu;
       gu0 = gu1;
       gu1 = gup;
       issue_op(n, rr + 1);
-      const int ip = gen.row0 + rr;
-      const bool xin = ip >= 1 && ip <= gen.cx;
-      const double iw = opaque((-gum / 2.0 - gen.kx) / gen.dx);
-      const double is = opaque((-o.b[1] / 2.0 - gen.ky) / gen.dy);
-      const double in = opaque((o.b[3] / 2.0 - gen.ky) / gen.dy);
-      const double ie = opaque((gup / 2.0 - gen.kx) / gen.dx);
-      const bool inner = xin && yin;
-      bc[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
-      bc[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);
-      bc[3] = inner ? in : ((xin && c == 0) ? 1.0 : 0.0);
-      bc[4] = inner ? ie : ((yin && ip == 0) ? 1.0 : 0.0);
-      bc[2] = inner ? gdiag : (xin ? (c == 0 ? gen.dg_bottom : gen.dg_top) : (yin ? gen.dg_left : 1.0));
+      form_coeffs(rr, gum, gup, o.b[1], o.b[3], bc);
     } else {
 #pragma unroll
-      for (int j = 0; j < 5; j++) bc[j] = o.b[j];
+      for (int j = 0; j < 5; j++) bc[j] = AHEAD ? bcn[j] : o.b[j];
       issue_op(n, rr + 1);
     }
     const int sl = (rr - rs + 2) & 3;
-    const double *s0 = sring + sl * kBlock;
-    const double vi = s0[t];
-    const double xs = c > 0 ? s0[tm] : 0.0;
-    const double xn = c + 1 < P ? s0[tp] : 0.0;
-    const double tin = row_sum(bc[0], bc[1], bc[2], bc[3], bc[4], sring[((sl + 3) & 3) * kBlock + t], xs, vi, xn,
-                               sring[((sl + 1) & 3) * kBlock + t]);
-    double u = tin / nrm;
+    double u = (AHEAD && W_AHEAD) ? wn : form_w(rr, bc);
 #pragma unroll
     for (int k = 0; k < NA; k++) {
       n.v[k] = __builtin_nontemporal_load(&Vh[(int64_t)k * ld + idxn]);
@@ -677,6 +726,13 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     n.s = __builtin_nontemporal_load(s_addr(rr + 3));
     sring[((sl + 2) & 3) * kBlock + t] = s_ok(rr + 2) ? sval : 0.0;  // row rr + 2 of s_NV
     __syncthreads();
+    if (AHEAD) {
+      // row rr + 1: its own velocities were requested at the top of this round (n.b), the row behind it too (n.gu)
+      form_coeffs(rr + 1, gu0, n.gu, n.b[1], n.b[3], bcn);
+      gu0 = gu1;
+      gu1 = n.gu;
+      if (W_AHEAD) wn = form_w(rr + 1, bcn);  // rows rr .. rr + 2 of s_NV are in the ring (rr + 2 since this round's first barrier)
+    }
     __syncthreads();
     emit_park(rr, o, 0.0);
   };
@@ -685,21 +741,46 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     const bool rowvalid = rr >= 0 && rr < rows;
     const bool active = rowvalid && ucol;
     const int64_t idxn = rowc(rr + 1) * pitch + off;
-    __syncthreads();
-    double u = xa[t];
+    // this half's group of the update (kGroupedFrom), summed while half 0 works on its own
     const int sl = (rr - rs + 2) & 3;
-    const double vi = sring[sl * kBlock + t];
+    const double vi = sring[sl * kBlock + t];  // row rr of s_NV: in the ring since two rounds
+    double pg = 0.0;
 #pragma unroll
     for (int k = 0; k < NB; k++) {
       n.v[k] = __builtin_nontemporal_load(&Vh[(int64_t)k * ld + idxn]);
-      u = u - lane_value(hpack, k) * o.v[k];
+      const double term = lane_value(hpack, k) * o.v[k];
+      pg = k == 0 ? term : pg + term;
     }
-    u = opaque(u - lane_value(hpack, NB) * vi);
+    pg = pg + lane_value(hpack, NB) * vi;
+    // The operator applied to the new vector on row q = rr - 1: rows q - 1 and q are in the ring since
+    // earlier rounds, so the first four terms of the row sum are formed here, before half 0's value arrives;
+    // the term of row q + 1 (this round's value) follows behind the barrier.
+    const int slot = (rr - rs + 1) & (kRing - 1);
+    double tvp;
+    {
+      const double *rq = ring + ((slot + kRing - 1) & (kRing - 1)) * kBlock;
+      const double *rm = ring + ((slot + kRing - 2) & (kRing - 1)) * kBlock;
+      const double us = c > 0 ? rq[tm] : 0.0;
+      const double un = c + 1 < P ? rq[tp] : 0.0;
+      double r = 0.0;
+      r = r + bp[0] * rm[t];
+      r = r + bp[1] * us;
+      r = r + bp[2] * rq[t];
+      r = r + bp[3] * un;
+      tvp = r;
+    }
+    __syncthreads();
+    double u = opaque(xa[t] - pg);
     const double uhv = o.uh;
     n.uh = *(u_halo != nullptr ? &u_halo[rowh(rr + 1) * pitch + off] : coef);
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? uhv : 0.0);
-    const int slot = (rr - rs + 1) & (kRing - 1);
     ring[slot * kBlock + t] = u;
+    tvs[t] = tvp + bp[4] * u;
+#pragma unroll
+    for (int j = 0; j < 5; j++) bp[j] = bcs[j * kBlock + t];
+    __syncthreads();
+    emit_park(rr, o, vi);
+    // The stores come last: nothing in the round waits for them (a row stays in the ring for kRing rounds).
     bool flush = rr - p0 + 1 == kStoreRows || rr == re - 1;
     if (geo.tick > 0 && (int32_t)(common_clock() - deadline) >= 0) {
       flush = true;
@@ -718,19 +799,6 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
       }
       p0 = rr + 1;
     }
-    {
-      // the operator applied to the new vector on row q = rr - 1 (its rows q - 1 and q are
-      // in the ring since earlier rounds, row q + 1 is this round's value)
-      const double *rq = ring + ((slot + kRing - 1) & (kRing - 1)) * kBlock;
-      const double *rm = ring + ((slot + kRing - 2) & (kRing - 1)) * kBlock;
-      const double us = c > 0 ? rq[tm] : 0.0;
-      const double un = c + 1 < P ? rq[tp] : 0.0;
-      tvs[t] = row_sum(bp[0], bp[1], bp[2], bp[3], bp[4], rm[t], us, rq[t], un, u);
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) bp[j] = bcs[j * kBlock + t];
-    __syncthreads();
-    emit_park(rr, o, vi);
   };
 
   if (half == 0) {
@@ -820,9 +888,23 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double 
     const double xn = col + 1 < P ? u_in[e + 1] : 0.0;
     const double tin = row_sum(b.w[i], b.s[i], b.c[i], b.n[i], b.e[i], xw, xs, xc, xn, xe);
     double u = tin / nrm;
+    constexpr int NG = NV >= kGroupedFrom ? (NV + 1) / 2 : NV + 1;  // as the sweeps group the update
+    double pg = 0.0;
 #pragma unroll
-    for (int k = 0; k < NV; k++) u = u - h[k] * vk[k];
-    u = u - h[NV] * xc;
+    for (int k = 0; k < NV; k++) {
+      const double term = h[k] * vk[k];
+      if (k < NG)
+        u = u - term;
+      else
+        pg = k == NG ? term : pg + term;
+    }
+    if (NG <= NV) {
+      const double term = h[NV] * xc;
+      pg = NG == NV ? term : pg + term;
+      u = u - pg;
+    } else {
+      u = u - h[NV] * xc;
+    }
     __builtin_nontemporal_store(u, &u_out[e]);
     a = fma(u, u, a);
   }
@@ -942,13 +1024,14 @@ int split_from() {
   return v < 12 ? 12 : v;
 }
 
-// Last step served by the 512-thread kernel: with 48 earlier vectors it needs scratch memory and the
-// 256-thread kernel is faster (5.72 against 6.13 ms on an 8192 x 8192 grid).  Env KRY_SPLIT_UPTO overrides.
+// Last step served by the 512-thread kernel: with 47 and 48 earlier vectors it needs scratch memory and the
+// 256-thread kernel is as fast or faster (5.66 against 5.75 ms, 5.77 against 6.13 ms on an 8192 x 8192 grid).
+// Env KRY_SPLIT_UPTO overrides.
 int split_upto() {
   static std::atomic<int> v{-1};
   int r = v.load(std::memory_order_relaxed);
   if (r < 0) {
-    r = getenv("KRY_SPLIT_UPTO") ? atoi(getenv("KRY_SPLIT_UPTO")) : 47;
+    r = getenv("KRY_SPLIT_UPTO") ? atoi(getenv("KRY_SPLIT_UPTO")) : 46;
     v.store(r, std::memory_order_relaxed);
   }
   return r;

@@ -226,6 +226,57 @@ void run_tick(const char *name, const double *V, long ld, int rows, int P, doubl
          ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9, (double)h[0] / reps / (nstrips * nbands), (double)h[1] / reps / (nstrips * nbands));
 }
 
+// Reads only, strip-major, at a chosen occupancy and a chosen number of requests in flight per wavefront: dynamic LDS
+// limits the resident workgroups per compute unit (the one-sweep kernels run 8 wavefronts per compute unit), and the
+// loop keeps DEPTH rows of K requests in flight (it requests row r + DEPTH before it uses row r).
+template <int K, int DEPTH>
+__global__ __launch_bounds__(256) void strip_occ(const double *__restrict__ V, long ld, int rows, int nstrips, int R,
+                                                 double *__restrict__ out) {
+  extern __shared__ double dyn[];
+  const int t = threadIdx.x;
+  const int strip = blockIdx.x % nstrips, band = blockIdx.x / nstrips;
+  const int rs = band * R, re = rs + R < rows ? rs + R : rows;
+  double acc = 0.0;
+  double v[DEPTH][K];
+  auto idx = [&](int r) -> long { return ((long)strip * rows + (r < rows ? r : rows - 1)) * 256 + t; };
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+    for (int k = 0; k < K; k++) v[d][k] = __builtin_nontemporal_load(&V[k * ld + idx(rs + d)]);
+  for (int rr = rs; rr < re; rr += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      const long in = idx(rr + d + DEPTH);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        acc += v[d][k];
+        v[d][k] = __builtin_nontemporal_load(&V[k * ld + in]);
+      }
+    }
+  }
+  if (acc == 12345.678) { out[blockIdx.x] = acc; dyn[t] = acc; }
+}
+
+template <int K, int DEPTH>
+void run_occ(const double *V, long ld, int rows, int P, double *out, int wg_per_cu) {
+  const int nstrips = 33;
+  const int nb = 1024 / nstrips;
+  const int R = (rows + nb - 1) / nb, nbands = (rows + R - 1) / R;
+  const size_t lds = wg_per_cu >= 8 ? 0 : (size_t)(160 * 1024 / wg_per_cu) - 1024;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&strip_occ<K, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int r = 0; r < 2; r++) hipLaunchKernelGGL((strip_occ<K, DEPTH>), dim3(nstrips * nbands), dim3(256), lds, 0, V, ld, rows, nstrips, R, out);
+  CHECK(hipDeviceSynchronize());
+  const int reps = 5;
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((strip_occ<K, DEPTH>), dim3(nstrips * nbands), dim3(256), lds, 0, V, ld, rows, nstrips, R, out);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipGetLastError());
+  const double bytes = 8.0 * K * (double)rows * nstrips * 256;
+  printf("K=%2d rows in flight %d (%3d requests per wavefront)  workgroups per compute unit %d  %8.1f us %7.1f GB/s (bytes moved)\n", K, DEPTH, K * DEPTH,
+         wg_per_cu, ms * 1e3 / reps, bytes * reps / (ms * 1e-3) / 1e9);
+}
+
 template <int K, int POL, int BURST, int TILED = 0, int RT = 0>
 void run(const char *name, const double *V, long ld, int rows, int P, double *out, double *Wr) {
   const int W = 249, nstrips = (P + W - 1) / W;
@@ -334,6 +385,18 @@ int main(int argc, char **argv) {
     run<32, 0, 16, 0, 1>("reads only, strip-major", Vt, ldt, rows, P, out, Wt);
     run<32, 0, 16, 0, 2>("reads only, strip-major + edges", Vt, ldt, rows, P, out, Wt);
     run<32, 2, 16, 1, 2>("nt, strip-major + edges", Vt, ldt, rows, P, out, Wt);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "occ")) {  // strip-major reads by occupancy and requests in flight
+    const long ldt = 34L * rows * 256;
+    double *Vt;
+    CHECK(hipMalloc((void **)&Vt, sizeof(double) * ldt * 32)); CHECK(hipMemset(Vt, 0, sizeof(double) * ldt * 32));
+    for (int w : {1, 2, 4, 8}) {
+      run_occ<16, 1>(Vt, ldt, rows, P, out, w);
+      run_occ<16, 2>(Vt, ldt, rows, P, out, w);
+      run_occ<16, 3>(Vt, ldt, rows, P, out, w);
+      run_occ<32, 1>(Vt, ldt, rows, P, out, w);
+    }
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "lat")) {
