@@ -464,9 +464,10 @@ constexpr int kUniformHalfUpto = 37;
 constexpr int kSplitFrom = 18;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
 // rows stored together: as many as the LDS left beside the parked vectors holds
 constexpr int split_store_rows(int nv) { return nv <= 42 ? 32 : 16; }
-// Vectors per half whose parked values wait in registers instead of LDS: where registers
-// are left, that buys the LDS for 32-row bursts up to 42 earlier vectors.
-constexpr int split_park_regs(int nv) { return nv >= 35 && nv <= 42 ? 4 : 0; }
+// Vectors per half whose parked values wait in registers instead of LDS, as many as the registers
+// hold: fewer LDS round trips in the dot-product phase (2 % up to 34 earlier vectors), and the LDS
+// for 32-row bursts up to 42 earlier vectors.
+constexpr int split_park_regs(int nv) { return nv < 18 ? 0 : (nv <= 24 ? 9 : (nv <= 30 ? 8 : (nv <= 34 ? 6 : (nv <= 42 ? 4 : 0)))); }
 
 template <int NV, bool GEN>
 __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Bands b, BandGen gen,
