@@ -1077,18 +1077,24 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv < kSplitFrom ? 2 : 1)));
   int best_nb = 1;
   double best = -1.0;
-  for (int r = 1; r <= 4 && cap * r <= 1024; r++) {
-    int nb = (cap * r) / g.nstrips;
+  // `slots` workgroups run at a time, `r` rounds of them
+  auto consider = [&](int slots, int r) {
+    int nb = (slots * r) / g.nstrips;
     if (nb > rows / 32) nb = rows / 32;  // bands of at least 32 rows
     if (nb < 1) nb = 1;
     const int R = (rows + nb - 1) / nb, nbands = (rows + R - 1) / R;
-    const int count = g.nstrips * nbands, rounds = (count + cap - 1) / cap;
-    const double score = (double)count / ((double)cap * rounds) * (double)R / (double)(R + kBandOverhead);
+    const int count = g.nstrips * nbands, rounds = (count + slots - 1) / slots;
+    const double score = (double)count / ((double)slots * rounds) * (double)R / (double)(R + kBandOverhead);
     if (score > best) {
       best = score;
       best_nb = nb;
     }
-  }
+  };
+  for (int r = 1; r <= 4 && cap * r <= 1024; r++) consider(cap, r);
+  // On a small grid the bands cannot get short enough to fill every slot (2048^2 with three slots per
+  // compute unit: 567 workgroups of 33 rows, three on some compute units and two on others); fewer, taller
+  // bands that give every compute unit the same number (two each: 504 of 37 rows) are faster then.
+  for (int k = 2; 256 * k < cap; k++) consider(256 * k, 1);
   g.R = (rows + best_nb - 1) / best_nb;
   g.nbands = (rows + g.R - 1) / g.R;
   g.tick = store_tick(nv);
