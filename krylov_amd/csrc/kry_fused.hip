@@ -1048,8 +1048,8 @@ int split_upto() {
 // The choice depends on nv alone, not on which kernel variant a knob selects.
 constexpr int kBandOverhead = 6;
 // Period of the common store clock for step nv, in 10 ns ticks (0: stores when the ring is full only).
-// Measured per instantiation on an 8192 x 8192 grid: 20 us for the short sweeps, 41 us up to 13 earlier
-// vectors, 61 us beyond; the shortest sweeps gain nothing.  Env KRY_STORE_TICK=period[,first_nv] overrides.
+// Measured per instantiation on an 8192 x 8192 grid: 20 us up to 7 earlier vectors, 31 us up to 12, 41 us up
+// to 18, 61 us up to 27, 82 us beyond; the shortest sweeps gain nothing.  Env KRY_STORE_TICK=period[,first_nv] overrides.
 int store_tick(int nv) {
   static std::atomic<int> period{-2}, from{0};
   if (period.load(std::memory_order_relaxed) == -2) {
@@ -1066,7 +1066,7 @@ int store_tick(int nv) {
   }
   const int p = period.load(std::memory_order_relaxed);
   if (p >= 0) return nv >= from.load(std::memory_order_relaxed) ? p : 0;
-  return nv <= 3 ? 0 : (nv <= 9 ? 2048 : (nv <= 13 ? 4096 : 6144));
+  return nv <= 3 ? 0 : (nv <= 7 ? 2048 : (nv <= 12 ? 3072 : (nv <= 18 ? 4096 : (nv <= 27 ? 6144 : 8192))));
 }
 FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
