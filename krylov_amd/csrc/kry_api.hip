@@ -836,7 +836,9 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   g->m = m;
   g->flags = flags;
   const bool one_sweep_possible = !(flags & KRY_GMRES_TDP) && m <= kFusedMaxM && m >= 3;
+  // (the kernels hold positions within a strip-major vector in 32-bit integers)
   if (one_sweep_possible && ctx->nranks == 1 && grid_rows > 0 && (int64_t)grid_rows * grid_cols == n &&
+      grid_rows < 8000000 && strip_major_size(grid_rows, grid_cols) < 2147483000LL &&
       !(getenv("KRY_STRIP_MAJOR") && atoi(getenv("KRY_STRIP_MAJOR")) == 0)) {
     // room for the strip-major form of every basis vector
     g->grid_rows = grid_rows;
