@@ -41,6 +41,14 @@
 // basis vectors, so that two wavefronts fit a SIMD where the first kernel runs with one);
 // both produce the same bits.
 //
+// Three things about how the sweeps use the memory system and the compute units:
+//  * the rows of the new vector wait in an LDS ring and are stored when a device-wide clock passes a
+//    multiple of a period (FusedGeom::tick), so that all workgroups write at the same moments;
+//  * the basis vectors and velocity snapshots may be stored strip by strip (FusedGeom::sm, StripMap):
+//    a workgroup then reads and writes whole aligned 2 KB lines that follow each other in memory;
+//  * from kGroupedFrom earlier vectors on the update is evaluated in two groups, one per half of
+//    the 512-thread workgroup, so that the halves work on it at the same time.
+//
 // Requirements, checked by the host: 5-band operator whose couplings across
 // the ends of a grid row (band s in column 0, band n in the last column) are
 // zero, m <= kFusedMaxM.
