@@ -217,6 +217,22 @@ int kry_gmres_get_one_sweep(const kry_gmres *g);
  * are returned in grid order.  Returns 1 if the basis of the last solve was stored that way,
  * else 0.  Environment KRY_STRIP_MAJOR=0 switches it off. */
 int kry_gmres_basis_strip_major(const kry_gmres *g);
+/* How the last Arnoldi step of a cycle obtains H(m, m-1) = ||w - sum_k h_k v_k||, the normalisation
+ * at the end of gram_schmidt (include/solver.hpp:209); no counterpart in the reference, which
+ * always forms the vector.  The vector of that step is not part of the solution (x = sum of m
+ * basis vectors, :153-159), only its norm enters the reduced problem, and modified Gram-Schmidt
+ * takes ||w||^2 down by h_k^2 per link: with one-sweep steps the solver of a step object
+ * therefore takes that norm as sqrt(||A v_{m-1}||^2 - sum_k h_k^2) from sums the last sweep has
+ * already formed and skips the closing pass over the basis, unless less than 1/64 of ||A v||^2
+ * is left (cancellation, e.g. near a breakdown), in which case the device itself falls back to
+ * forming the vector.  kry_gmres_subspace_vector(g, m) forms the vector on demand, with the same
+ * bits as the closing pass.  Stand-alone solvers (kry_gmres_create) always form the vector.
+ * on = 0 switches the shortcut off (environment: KRY_NORM_FROM_SUMS=0).  The getter returns 1
+ * when the shortcut is available and on; kry_gmres_last_norm_from_sums reads back (it waits for
+ * the device) whether the last solve's final cycle used it (1) or fell back (0). */
+int kry_gmres_set_norm_from_sums(kry_gmres *g, int on);
+int kry_gmres_get_norm_from_sums(const kry_gmres *g);
+int kry_gmres_last_norm_from_sums(kry_gmres *g, int *used);
 /* Tuning knob without a counterpart in the reference: from this step of a cycle on
  * the one-sweep steps run as workgroups of 512 threads whose halves split the basis
  * vectors (two wavefronts per SIMD where the 256-thread kernel fits one); every

@@ -275,7 +275,31 @@ struct kry_gmres {
   int grid_rows = 0, grid_cols = 0;
   bool strips_capable = false, strips = false;
   double *v0 = nullptr;
+  // The norm of a cycle's last vector from the last sweep's sums (launch_fused_coeffs) instead of from the
+  // closing kernel: for solves with the operator the solver is bound to (bound_op: the operator of the step
+  // object that owns the solver, which lives as long as the solver does), because the vector itself is then
+  // formed only when somebody asks for it (kry_gmres_subspace_vector), which takes the operator again.
+  // fskip: the device flag that turns the closing kernel into a no-op; last_pending: slot m of the basis
+  // has not been filled by the last solve.
+  kry_op *bound_op = nullptr;
+  bool norm_from_sums = true;
+  int *fskip = nullptr;
+  bool last_pending = false;
 };
+
+// What the host keeps about the contents of a solver's basis: written when a solve is queued, and
+// therefore stale after a captured step is replayed if something else used the solver in between.
+struct BasisState {
+  int nvec = 0;
+  bool scaled = false, strips = false, last_pending = false;
+};
+static BasisState basis_state(const kry_gmres *g) { return BasisState{g->nvec, g->scaled, g->strips, g->last_pending}; }
+static void set_basis_state(kry_gmres *g, const BasisState &b) {
+  g->nvec = b.nvec;
+  g->scaled = b.scaled;
+  g->strips = b.strips;
+  g->last_pending = b.last_pending;
+}
 
 struct kry_ie {
   kry_ctx *ctx = nullptr;
@@ -309,6 +333,7 @@ struct kry_ie {
   hipGraphExec_t graph_exec = nullptr;
   double graph_dt = 0.0;
   uint64_t graph_epoch = 0;  // g_config_epoch at capture
+  BasisState graph_basis;    // what a replay leaves in the solver's basis (recorded at capture)
   bool whole() const { return g.row0 == 0 && g.rows == g.cx + 2; }
 };
 
@@ -807,6 +832,7 @@ static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld + g
 // operator with the dots of all earlier vectors in one kernel (at most kMgsBlock of
 // them), and at least one full sweep has to follow before the closing one.
 static int fused_from_max(int m) { return m - 2 < kMgsBlock - 1 ? m - 2 : kMgsBlock - 1; }
+static bool norm_from_sums(const kry_gmres *g, const kry_op *op);
 
 extern "C" {
 
@@ -893,6 +919,9 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     if (st == KRY_OK) st = dev_alloc(&g->fparts, (int64_t)kFusedRed * kMaxParts);
     if (st == KRY_OK) st = dev_alloc(&g->ftot, kFusedRed);
     if (st == KRY_OK) st = dev_alloc(&g->fcoef, kFusedCoef);
+    if (st == KRY_OK && hipMalloc((void **)&g->fskip, 256) != hipSuccess) st = fail(KRY_ERR_HIP, "hipMalloc of a flag failed");
+    if (st == KRY_OK) (void)hipMemsetAsync(g->fskip, 0, 256, ctx->stream);
+    if (const char *e = getenv("KRY_NORM_FROM_SUMS")) g->norm_from_sums = atoi(e) != 0;  // experimentation knob
     if (st == KRY_OK) g->fused_from = from < 0 ? -1 : from;
   }
   if (st != KRY_OK) {
@@ -935,6 +964,7 @@ void kry_gmres_destroy(kry_gmres *g) {
                     g->dd, g->ud, g->R, g->G, g->fparts, g->ftot, g->fcoef, g->fsigma};
   for (double *p : bufs) (void)hipFree(p);
   if (g->ext) (void)hipFree(g->ext);
+  if (g->fskip) (void)hipFree(g->fskip);
   if (g->ext_h) (void)hipHostFree(g->ext_h);
   if (g->own_tri) {
     (void)hipFree(g->lo);
@@ -966,6 +996,27 @@ int kry_gmres_set_one_sweep(kry_gmres *g, int first_step) {
   if (!g->fparts)
     return fail(KRY_ERR_STATE, "one-sweep steps need a solver without preconditioner and 3 <= num_iters <= %d", kFusedMaxM);
   g->fused_from = first_step > fused_from_max(g->m) ? fused_from_max(g->m) : first_step;
+  return KRY_OK;
+}
+
+int kry_gmres_set_norm_from_sums(kry_gmres *g, int on) {
+  if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
+  config_changed();
+  g->norm_from_sums = on != 0;
+  return KRY_OK;
+}
+
+int kry_gmres_get_norm_from_sums(const kry_gmres *g) {
+  return g && g->fused_from >= 0 && g->bound_op && norm_from_sums(g, g->bound_op) ? 1 : 0;
+}
+
+int kry_gmres_last_norm_from_sums(kry_gmres *g, int *used) {
+  if (!g || !used) return fail(KRY_ERR_INVALID, "NULL argument");
+  *used = 0;
+  if (!g->last_pending) return KRY_OK;  // the last solve did not take the shortcut at all
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpyAsync(used, g->fskip, sizeof(int), hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
   return KRY_OK;
 }
 
@@ -1067,8 +1118,7 @@ static int finish_parts(kry_gmres *g, const double **part, int nq, int *np) {
 static void store_v0(kry_gmres *g, const double *src, const double *part, int np, double *out) {
   hipStream_t st = g->ctx->stream;
   if (g->strips) {
-    launch_scale_from(st, src, g->v0, part, np, g->n, out);
-    launch_to_strips(st, g->v0, basis(g, 0), g->grid_rows, g->grid_cols, false);
+    launch_scale_to_strips(st, src, g->v0, basis(g, 0), part, np, g->grid_rows, g->grid_cols, out);
   } else {
     launch_scale_from(st, src, basis(g, 0), part, np, g->n, out);
   }
@@ -1086,6 +1136,7 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   }
   g->nvec = 1;
   g->scaled = false;
+  g->last_pending = false;
   // Every vector starts a cycle normalised; the one-sweep steps overwrite the scale factors
   // of the slots they fill.  A monitored solve may stop before they run (their kernels,
   // the hand-over included, are predicated), so there the factors are reset here; a fixed
@@ -1195,6 +1246,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       store_v0(g, g->w, pin, np, g->beta);
       g->nvec = 1;
       g->scaled = false;
+      g->last_pending = false;
       if (g->fsigma) launch_fill(st, g->fsigma, 1.0, kFusedCoef);
     }
     {
@@ -1261,9 +1313,22 @@ static bool strips_usable(const kry_gmres *g, const kry_op *op) {
          op->use_gen && op->has_gen_strips && op->rows == g->grid_rows && op->cols == g->grid_cols;
 }
 
+// Whether a solve with this operator takes the norm of the cycle's last vector from the last sweep's sums.
+static bool norm_from_sums(const kry_gmres *g, const kry_op *op) {
+  return g->norm_from_sums && g->fskip != nullptr && op == g->bound_op && g->m >= 2 && fused_sweep_has_tt(g->m - 2);
+}
+
+// The closing kernel of a cycle: the update of step m - 1 on the whole vector (slot m) and its squared norm.
+static void launch_close_whole(kry_gmres *g, kry_op *op, int *np, const int *skip) {
+  const Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
+  const StripMap smap = g->strips ? strip_map(op->rows, op->cols) : StripMap();
+  launch_arnoldi_close(g->ctx->stream, g->m - 1, b, basis(g, 0), g->ld, g->fcoef, g->n, op->cols, 0, g->n,
+                       g->ctx->nranks > 1, g->fparts, np, g->strips ? &smap : nullptr, skip);
+}
+
 // Totals of nq quantities from the partial sums of a one-sweep kernel, summed over the ranks.
-static int fused_totals(kry_gmres *g, int nq, int np) {
-  launch_reduce_parts_wide(g->ctx->stream, g->fparts, nq, np, g->ftot);
+static int fused_totals(kry_gmres *g, int nq, int np, const int *skip = nullptr) {
+  launch_reduce_parts_wide(g->ctx->stream, g->fparts, nq, np, g->ftot, skip);
   if (g->ctx->nranks > 1) KCHK(comm_allreduce(g->ctx, g->ftot, nq, KRY_REDUCE_SUM));
   return KRY_OK;
 }
@@ -1297,10 +1362,12 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
       op_apply_async(op, basis(g, i0), g->w, i0 + 1, basis(g, 0), g->ld, g->fparts, &np, g->halo_row > 0);
   }
   KCHK(fused_totals(g, 2 * (i0 + 1) - 1, np));
-  const StripMap smap = g->strips ? strip_map(op->rows, op->cols) : StripMap();
+  // the last step's norm from the last sweep's sums; the closing kernel then only runs where that cancels
+  const int *skip = norm_from_sums(g, op) ? g->fskip : nullptr;
   for (int i = i0; i < m; i++) {
     const bool boot = i == i0;
-    launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef, g->fsigma);
+    launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef, g->fsigma,
+                        (skip && i == m - 1) ? g->fskip : nullptr);
     if (ext && !boot) {
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
       launch_givens(st, g->H, m, i - 1, R, rot_c, rot_s, gv, g->ext);
@@ -1336,15 +1403,15 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
         launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks, gen,
                              kSweepAll, g->strips);
       }
-      KCHK(fused_totals(g, 2 * i + 4, np));
+      KCHK(fused_totals(g, 2 * i + 4 + (fused_sweep_has_tt(i) ? 1 : 0), np));
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-      launch_arnoldi_close(st, i, b, basis(g, 0), g->ld, g->fcoef, n, op->cols, 0, n, ranks, g->fparts, &np,
-                           g->strips ? &smap : nullptr);
+      launch_close_whole(g, op, &np, skip);
     }
   }
-  KCHK(fused_totals(g, 1, np));
-  launch_fused_finish(st, g->ftot, m, g->H, g->fsigma);
+  KCHK(fused_totals(g, 1, np, skip));
+  launch_fused_finish(st, g->ftot, m, g->H, g->fsigma, skip);
+  g->last_pending = skip != nullptr;
   if (ext) {
     ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
     launch_givens(st, g->H, m, m - 1, R, rot_c, rot_s, gv, g->ext);
@@ -1480,6 +1547,14 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
   if (!g || !out_host) return fail(KRY_ERR_INVALID, "NULL argument");
   if (i < 0 || i >= g->nvec) return fail(KRY_ERR_INVALID, "subspace vector %d does not exist (%d vectors)", i, g->nvec);
   HIPCHK(hipSetDevice(g->ctx->device));
+  if (i == g->m && g->last_pending) {
+    // the last solve took the norm of this vector from sums: form the vector now (its coefficients
+    // are still in place, and the operator it takes is the one the solver is bound to)
+    int np = 0;
+    launch_close_whole(g, g->bound_op, &np, nullptr);
+    KCHK(launch_ok("kry_gmres_subspace_vector"));
+    g->last_pending = false;
+  }
   const double *src = basis(g, i);
   if (g->strips) {
     launch_unscale_strips(g->ctx->stream, src, g->scaled ? g->fsigma : nullptr, i, g->w, g->grid_rows, g->grid_cols);
@@ -1578,7 +1653,9 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
       bytes[KRY_K_FUSED] += (1.0 + i) * N + opf + N;
       launches[KRY_K_FUSED] += 1;
     }
-    bytes[KRY_K_MGS_LAST] += m * N + opb + N;  // closing sweep: the m stored vectors and the operator read; the new vector written
+    // closing sweep: the m stored vectors and the operator read, the new vector written -- unless the norm it
+    // exists for comes from the last sweep's sums (the launch then returns at once)
+    if (!norm_from_sums(g, op)) bytes[KRY_K_MGS_LAST] += m * N + opb + N;
     launches[KRY_K_MGS_LAST] += 1;
   }
   // one normalisation per chain step (none after the one-sweep steps) + ||b|| and v_0 = b/||b||
@@ -1702,6 +1779,7 @@ int kry_ie_create_slab(kry_ctx *ctx, double c1x, double c1y, double c2x, double 
     op->slab = !ie->whole();
     ie->op = op;
     if (m > 0) st = gmres_create(ctx, ie->nloc, m, flags, P, &ie->solver, ie->g.rows, P);
+    if (st == KRY_OK && ie->solver) ie->solver->bound_op = op;
   }
   if (st != KRY_OK) {
     kry_ie_destroy(ie);
@@ -1844,9 +1922,13 @@ static int ie_step_async(kry_ie *ie, double dt) {
       if (e != hipSuccess) return fail(KRY_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
       ie->graph_dt = dt;
       ie->graph_epoch = epoch;
+      ie->graph_basis = basis_state(ie->solver);
     }
     ie->bc_dirty = false;  // the graph always re-uploads the staged boundary values
     HIPCHK(hipGraphLaunch(ie->graph_exec, st));
+    // A replay refills the basis as the captured solve did, whatever used the solver since (the step-wise
+    // interface, a solve with another operator): the host's notes about the basis follow the replay.
+    set_basis_state(ie->solver, ie->graph_basis);
   }
   ie->pending = true;
   ie->time += dt;  // include/time_disc.hpp:287 (after the solve: BCs were taken at the old time)

@@ -10,8 +10,8 @@
 //     s_{i+1} = w - c_0 s_0 - ... - c_i s_i,  c_k = h_k / sigma_k
 //                                              (modified Gram-Schmidt order)
 //     t_{i+1} = A s_{i+1}
-// and accumulates <t_{i+1}, s_k>, <s_k, s_{i+1}> (k <= i), <t_{i+1}, s_{i+1}>
-// and <s_{i+1}, s_{i+1}>.  From those sums the next step's coefficients follow
+// and accumulates <t_{i+1}, s_k>, <s_k, s_{i+1}> (k <= i), <t_{i+1}, s_{i+1}>,
+// <s_{i+1}, s_{i+1}> and <t_{i+1}, t_{i+1}>.  From those sums the next step's coefficients follow
 // without touching a vector again (k_fused_coeffs): with n = sigma_{i+1},
 //     <A v_{i+1}, v_k> = <t, s_k> / (sigma_k n),   <A v_{i+1}, v_{i+1}> = <t, s> / n^2,
 //     <v_k, v_{i+1}>   = <s_k, s> / (sigma_k n)    (the carried Gram column),
@@ -20,6 +20,12 @@
 // the blocked sweeps do within one group.  Whoever needs v_k divides by sigma_k
 // (kry_gmres_subspace_vector), or divides the coefficient that multiplies it
 // (the final combination x = sum y_k v_k).
+// The last step of a cycle only needs the NORM of its vector (H(m, m-1); the vector
+// itself is not part of x): modified Gram-Schmidt takes ||w||^2 down by h_k^2 per
+// link, so that norm is sqrt(||A v_{m-1}||^2 - sum_k h_k^2) with ||A v_{m-1}||^2 =
+// <t, t> / sigma_{m-1}^2 from the last sweep.  k_fused_coeffs forms it and raises a
+// device flag that turns the closing kernel (k_arnoldi_close on the whole vector) into
+// a no-op, unless the subtraction cancels (less than 1/64 of ||A v||^2 left).
 //
 // t = A u needs u at the four neighbours, so the sweep is tiled in two
 // dimensions: a workgroup owns a strip of at most 252 columns (thread = column,
@@ -75,6 +81,12 @@ constexpr int kGroupedFrom = 12;
 // by registers; a workgroup needs (nv + 1 + rows + 4) x 2 KB + the reduction scratch of the
 // 160 KB); the steps were measured per instantiation on an 8192 x 8192 grid.
 constexpr int store_rows(int nv) { return nv <= 7 ? 8 : (nv <= 18 ? 16 : (nv <= 21 ? 8 : (nv <= 29 ? 32 : 16))); }
+
+// Whether the sweep of step nv also accumulates <t, t> (the last of its partial sums), from which the norm of a
+// cycle's last vector follows without the closing kernel.  The 512-thread kernel for 41 earlier vectors has no
+// register left for one more accumulator (it would spill), so a cycle whose last sweep is that one (m = 43)
+// keeps the closing kernel.  A property of the step, not of the kernel variant that serves it.
+constexpr bool sweep_has_tt(int nv) { return nv != 41; }
 
 struct FusedGeom {
   int rows, P;     // padded grid: rows x P, unknown k = row * P + column
@@ -145,8 +157,10 @@ __device__ __forceinline__ double gdiag_of(const BandGen &gen) { return *gen.cdi
 // of G and of H, H[i][i-1] = sigma_i, coef[k] = h_k / sigma_k (k <= i) and
 // coef[kFusedNormSlot] = sigma_i.  Called by every thread of a workgroup; the first
 // wavefront does the recurrence.  gs: i (i + 1) doubles of LDS.
+constexpr double kNormFromSumsMin = 1.0 / 64.0;  // share of ||A v||^2 the norm from sums has to keep
+
 __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int boot, double *G, int gld, double *H,
-                                                  int m, double *coef, double *sigma, double *gs) {
+                                                  int m, double *coef, double *sigma, double *gs, int *norm_flag) {
   const int lane = threadIdx.x;  // only lanes of the first wavefront own a vector
   const int gp = i + 1;          // row pitch of gs
   const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
@@ -183,6 +197,22 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
     coef[kFusedNormSlot] = nrm;
     if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
   }
+  if (norm_flag != nullptr) {
+    // ||A v_i - sum_k h_k v_k||^2 = ||A v_i||^2 - sum_k h_k^2;  <t, t> is the last total of the previous sweep
+    double hs = lane <= i ? v * v : 0.0;
+    hs = __shfl(wave_sum(hs), 0, 64);
+    const double ww = boot ? 0.0 : tot[2 * i + 2] / nrm / nrm;
+    const double r2 = ww - hs;
+    const bool ok = !boot && r2 >= kNormFromSumsMin * ww && ww > 0.0 && ww <= 1.7e308;  // false for anything not finite
+    if (lane == 0) {
+      *norm_flag = ok ? 1 : 0;
+      if (ok) {
+        const double nn = sqrt(r2);
+        sigma[i + 1] = nn;
+        H[(size_t)(i + 1) * m + i] = nn;
+      }
+    }
+  }
 }
 
 // NV: step number; s_0..s_{NV-1} are read from V, s_NV from u_in (it is slot NV of the
@@ -194,7 +224,7 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
 // s_halo: the rows in front of the first / behind the last grid row exist in memory
 // (a neighbouring rank's rows of s_NV, zeros beyond the mesh).
 // part layout (q * nstrips * nbands + band * nstrips + strip): q <= NV: <t, s_q>;  NV+1: <t, u>;
-// NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>   (t = A u).
+// NV+2+a, a <= NV: <s_a, u>;  2 NV + 3: <u, u>;  2 NV + 4: <t, t>   (t = A u).
 // GEN: the band entries of interior cells are evaluated from the recipe `gen` (velocity
 // snapshots; the operations of k_offdiag, so the same bits) and those of ghost rows and
 // columns follow from their position (a 1 towards the interior, the diagonal 2w - 1 of
@@ -219,7 +249,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
                                                           const double *__restrict__ u_halo, int s_halo,
                                                           const int *__restrict__ stop) {
   if (stopped(stop)) return;
-  constexpr int NQ = 2 * NV + 4;
+  constexpr bool TT = sweep_has_tt(NV);
+  constexpr int NQ = 2 * NV + 4 + (TT ? 1 : 0);
   extern __shared__ double lds[];
   double *keep = lds;                               // (NV + 1) x kBlock: s_k of the previous row
   constexpr int kStoreRows = store_rows(NV), kRing = kStoreRows;
@@ -445,6 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       }
       acc[NV + 1] = fma(uq, tv, acc[NV + 1]);
       acc[2 * NV + 3] = fma(uq, uq, acc[2 * NV + 3]);
+      if (TT) acc[NQ - 1] = fma(tv, tv, acc[NQ - 1]);
     }
 #pragma unroll
     for (int k = 0; k < NV; k++) keep[k * kBlock + t] = o.v[k];
@@ -487,7 +519,8 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
                                                                 const double *__restrict__ u_halo, int s_halo,
                                                                 const int *__restrict__ stop) {
   if (stopped(stop)) return;
-  constexpr int NQ = 2 * NV + 4;
+  constexpr bool TT = sweep_has_tt(NV);
+  constexpr int NQ = 2 * NV + 4 + (TT ? 1 : 0);
   constexpr int NA = (NV + 1) / 2, NB = NV - NA;  // vectors of half 0: [0, NA), of half 1: [NA, NV) and s_NV
   static_assert(NB >= 1, "both halves need a vector");
   constexpr int kStoreRows = split_store_rows(NV), kRing = kStoreRows;
@@ -559,8 +592,8 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     sring[2 * kBlock + t] = s_ok(rs) ? d2 : 0.0;
   }
   // accumulators of this half: <t, s_k> and <s_k, u> of its vectors (index NB of half 1: s_NV),
-  // half 0 also <t, u> and <u, u>
-  double aT[NA + 1], aS[NA + 1], aTU = 0.0, aUU = 0.0;
+  // half 0 also <t, u> and <u, u>, half 1 <t, t>
+  double aT[NA + 1], aS[NA + 1], aTU = 0.0, aUU = 0.0, aTT = 0.0;
 #pragma unroll
   for (int k = 0; k <= NA; k++) aT[k] = aS[k] = 0.0;
 
@@ -647,6 +680,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
         const double sk = keep[kRowS * kBlock + t];
         aT[NB] = fma(sk, tv, aT[NB]);
         aS[NB] = fma(sk, uq, aS[NB]);
+        if (TT) aTT = fma(tv, tv, aTT);
       }
     }
 #pragma unroll
@@ -844,6 +878,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   } else {
     put(NV, aT[NB]);
     put(2 * NV + 2, aS[NB]);
+    if (TT) put(2 * NV + 4, aTT);
   }
   __syncthreads();
   if (threadIdx.x < NQ) {
@@ -873,8 +908,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double 
                                                            double *__restrict__ u_out, int64_t n, int P,
                                                            int64_t k0, int64_t cnt, int s_halo,
                                                            double *__restrict__ part,
-                                                           const int *__restrict__ stop, StripMap map) {
-  if (stopped(stop)) return;
+                                                           const int *__restrict__ stop, StripMap map,
+                                                           const int *__restrict__ skip) {
+  if (stopped(stop) || stopped(skip)) return;
   __shared__ double s[kBlock / 64];
   double h[NV + 1];
 #pragma unroll
@@ -937,9 +973,35 @@ __global__ __launch_bounds__(kBlock) void k_to_strips(const double *__restrict__
   }
 }
 
-// x (grid order) = sum_k y_k V_k of strip-major vectors; per element the operations of k_combine.  A
-// workgroup takes one row of one strip at a time (lane = position in the row), so every read is one
-// aligned 2 KB line.
+// v = src / sqrt(sum of part), stored twice in one pass over src: strip-major (every position of every row of
+// every block, zero outside the grid and in the blocks' first and last row) and in grid order (the hand-over's
+// operator kernel reads that copy).  True division, as normalize() in include/matrix.hpp:54-60; *out = the norm.
+__global__ __launch_bounds__(kBlock) void k_scale_to_strips(const double *__restrict__ src, double *__restrict__ grid_dst,
+                                                             double *__restrict__ strip_dst,
+                                                             const double *__restrict__ part, int np, int rows, int P,
+                                                             StripMap map, double *__restrict__ out,
+                                                             const int *__restrict__ stop) {
+  if (stopped(stop)) return;
+  __shared__ double sh[kBlock / 64];
+  const double nrm = sqrt(sum_parts(part, np, sh));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out) *out = nrm;
+  const int lt = threadIdx.x;
+  const int64_t total = (int64_t)map.nstrips * (rows + 2);
+  for (int64_t q = blockIdx.x; q < total; q += gridDim.x) {
+    const int s = (int)(q / (rows + 2)), r = (int)(q % (rows + 2)) - 1;
+    const int c = s * map.W - 2 + lt;
+    const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
+    const bool ok = c >= 0 && c < P && lt <= wown + 3 && r >= 0 && r < rows;
+    double v = 0.0;
+    if (ok) v = __builtin_nontemporal_load(&src[(int64_t)r * P + c]) / nrm;
+    __builtin_nontemporal_store(v, &strip_dst[(int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt]);
+    if (ok && lt >= 2 && lt < wown + 2) __builtin_nontemporal_store(v, &grid_dst[(int64_t)r * P + c]);
+  }
+}
+
+// x (grid order) = sum_k y_k V_k of strip-major vectors; per element the operations of k_combine.  Lanes move
+// 16 bytes: 128 of them cover the 256 positions of a strip's row (one aligned 2 KB line per vector), so the two
+// halves of a workgroup take two consecutive rows of a strip at a time.
 __global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restrict__ V, int64_t ld,
                                                             const double *__restrict__ y, int m,
                                                             double *__restrict__ x, int rows, int P,
@@ -952,19 +1014,27 @@ __global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restr
   }
   for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = sigma != nullptr ? y[i] / sigma[i] : y[i];
   __syncthreads();
-  const int lt = threadIdx.x;
-  const int64_t total = (int64_t)map.nstrips * rows;
+  const int half = threadIdx.x >> 7, lt = (threadIdx.x & 127) * 2;  // this lane's positions: lt and lt + 1
+  const int pairs = (rows + 1) / 2;
+  const int64_t total = (int64_t)map.nstrips * pairs;
   for (int64_t q = blockIdx.x; q < total; q += gridDim.x) {
-    const int s = (int)(q / rows), r = (int)(q % rows);
+    const int s = (int)(q / pairs), r = (int)(q % pairs) * 2 + half;
     const int c = s * map.W - 2 + lt;
     const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
-    if (lt < 2 || lt >= wown + 2) continue;  // the strip's own columns only
+    // the strip's own columns only
+    const bool own0 = lt >= 2 && lt < wown + 2, own1 = lt + 1 >= 2 && lt + 1 < wown + 2;
+    if (r >= rows || !(own0 || own1)) continue;
     const int64_t e = (int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt;
     const int64_t i = (int64_t)r * P + c;
-    double acc = accumulate ? x[i] : 0.0;
+    double a0 = (accumulate && own0) ? x[i] : 0.0, a1 = (accumulate && own1) ? x[i + 1] : 0.0;
 #pragma unroll 8
-    for (int k = 0; k < m; k++) acc = acc + ys[k] * __builtin_nontemporal_load(&V[(int64_t)k * ld + e]);
-    __builtin_nontemporal_store(acc, &x[i]);
+    for (int k = 0; k < m; k++) {
+      const d2 v = ld_nt(reinterpret_cast<const d2 *>(&V[(int64_t)k * ld + e]));
+      a0 = a0 + ys[k] * v.x;
+      a1 = a1 + ys[k] * v.y;
+    }
+    if (own0) __builtin_nontemporal_store(a0, &x[i]);
+    if (own1) __builtin_nontemporal_store(a1, &x[i + 1]);
   }
 }
 
@@ -979,8 +1049,9 @@ __global__ __launch_bounds__(kBlock) void k_unscale_strips(const double *__restr
 // tot[q] = sum of part[q * np .. q * np + np): one workgroup per quantity.
 __global__ __launch_bounds__(kBlock) void k_reduce_parts_wide(const double *__restrict__ part, int np,
                                                                double *__restrict__ tot,
-                                                               const int *__restrict__ stop) {
-  if (stopped(stop)) return;
+                                                               const int *__restrict__ stop,
+                                                               const int *__restrict__ skip) {
+  if (stopped(stop) || stopped(skip)) return;
   __shared__ double s[kBlock / 64];
   const int q = blockIdx.x;
   double a = 0.0;
@@ -996,16 +1067,17 @@ __global__ __launch_bounds__(64) void k_fused_coeffs(const double *__restrict__ 
                                                       double *__restrict__ H, int m,
                                                       double *__restrict__ coef,
                                                       double *__restrict__ sigma,
-                                                      const int *__restrict__ stop) {
+                                                      const int *__restrict__ stop, int *__restrict__ norm_flag) {
   if (stopped(stop)) return;
   __shared__ double gs[kFusedMaxM * (kFusedMaxM + 1)];
-  fused_coeffs_body(tot, i, boot, G, gld, H, m, coef, sigma, gs);
+  fused_coeffs_body(tot, i, boot, G, gld, H, m, coef, sigma, gs, norm_flag);
 }
 
 // End of a cycle: sigma_m = ||s_m|| from the closing kernel's total, H[m][m-1] = sigma_m.
 __global__ __launch_bounds__(64) void k_fused_finish(const double *__restrict__ tot, int m, double *__restrict__ H,
-                                                      double *__restrict__ sigma, const int *__restrict__ stop) {
-  if (stopped(stop)) return;
+                                                      double *__restrict__ sigma, const int *__restrict__ stop,
+                                                      const int *__restrict__ skip) {
+  if (stopped(stop) || stopped(skip)) return;
   if (threadIdx.x == 0) {
     const double nrm = sqrt(tot[0]);
     sigma[m] = nrm;
@@ -1114,7 +1186,7 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
                     int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
                     const double *u_halo, int s_halo, int launch_bands) {
   constexpr size_t lds =
-      sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 4) * (kBlock / 64));
+      sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 5) * (kBlock / 64));
   static_assert(lds <= 160 * 1024, "LDS of one compute unit");
   static std::atomic<uint64_t> configured{0};
   allow_lds(&k_arnoldi_fused<NV, GEN>, lds, configured, "LDS size of the one-sweep kernel");
@@ -1122,7 +1194,7 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
   if constexpr (NV >= 12 && (GEN || NV <= 46)) {
     if (NV >= split_from() && NV <= split_upto()) {
       constexpr size_t lds2 = sizeof(double) * ((size_t)(NV + 1 - 2 * split_park_regs(NV)) * kBlock +
-                                                (split_store_rows(NV) + 4 + 7) * kBlock + (2 * NV + 4) * 4);
+                                                (split_store_rows(NV) + 4 + 7) * kBlock + (2 * NV + 5) * 4);
       static_assert(lds2 <= 160 * 1024, "LDS of one compute unit");
       static std::atomic<uint64_t> configured2{0};
       allow_lds(&k_arnoldi_split<NV, GEN>, lds2, configured2, "LDS size of the 512-thread one-sweep kernel");
@@ -1147,13 +1219,14 @@ struct CloseArgs {
   double *part;
   int grid;
   StripMap map;
+  const int *skip;
 };
 
 template <int NV>
 void launch_close_t(hipStream_t st, const CloseArgs &a) {
   hipLaunchKernelGGL(k_arnoldi_close<NV>, dim3(a.grid), dim3(kBlock), 0, st, a.b, a.V, a.ld, a.V + (int64_t)NV * a.ld,
                      a.coef, const_cast<double *>(a.V) + (int64_t)(NV + 1) * a.ld, a.n, a.P, a.k0, a.cnt, a.s_halo,
-                     a.part, launch_predicate_current(), a.map);
+                     a.part, launch_predicate_current(), a.map, a.skip);
 }
 
 template <int NV = kFusedMaxM - 1>
@@ -1188,6 +1261,8 @@ struct FusedTable<-1> {
 
 }  // namespace
 
+bool fused_sweep_has_tt(int nv) { return sweep_has_tt(nv); }
+
 void set_split_from(int first_step) { g_split_from.store(first_step < 0 ? kSplitFrom : first_step); }
 int get_split_from() { return split_from(); }
 
@@ -1217,10 +1292,18 @@ void launch_to_strips(hipStream_t st, const double *src, double *dst, int rows, 
                      src_has_halo_rows ? 1 : 0);
 }
 
+void launch_scale_to_strips(hipStream_t st, const double *src, double *grid_dst, double *strip_dst, const double *part,
+                            int nparts, int rows, int cols, double *out) {
+  const StripMap m = strip_map(rows, cols);
+  const int64_t total = (int64_t)m.nstrips * (rows + 2);
+  hipLaunchKernelGGL(k_scale_to_strips, dim3((unsigned)(total < 2048 ? total : 2048)), dim3(kBlock), 0, st, src, grid_dst,
+                     strip_dst, part, nparts, rows, cols, m, out, launch_predicate_current());
+}
+
 void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
                            int cols, const int *count, bool accumulate, const double *sigma) {
   const StripMap map = strip_map(rows, cols);
-  const int64_t total = (int64_t)map.nstrips * rows;
+  const int64_t total = (int64_t)map.nstrips * ((rows + 1) / 2);
   // 1024 workgroups: four per compute unit, each walking a share of the (strip, row) pairs
   hipLaunchKernelGGL(k_combine_strips, dim3((unsigned)(total < 1024 ? total : 1024)), dim3(kBlock), 0, st, V, ld, y, m, x, rows,
                      cols, count, accumulate ? 1 : 0, sigma, map);
@@ -1261,26 +1344,26 @@ bool fused_bands_splittable(int nv, int rows, int cols) { return fused_geom(rows
 
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
                           int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts,
-                          const StripMap *map) {
+                          const StripMap *map, const int *skip) {
   int grid = grid_for(cnt);
   if (grid > 1024) grid = 1024;
-  const CloseArgs a{b, V, ld, coef, n, cols, k0, cnt, has_halo ? 1 : 0, part, grid, map ? *map : StripMap()};
+  const CloseArgs a{b, V, ld, coef, n, cols, k0, cnt, has_halo ? 1 : 0, part, grid, map ? *map : StripMap(), skip};
   FusedTable<>::close(nv, st, a);
   *nparts = grid;
 }
 
-void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot) {
-  hipLaunchKernelGGL(k_reduce_parts_wide, dim3(nq), dim3(kBlock), 0, st, part, np, tot, launch_predicate_current());
+void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot, const int *skip) {
+  hipLaunchKernelGGL(k_reduce_parts_wide, dim3(nq), dim3(kBlock), 0, st, part, np, tot, launch_predicate_current(), skip);
 }
 
 void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
-                         int m, double *coef, double *sigma) {
+                         int m, double *coef, double *sigma, int *norm_flag) {
   hipLaunchKernelGGL(k_fused_coeffs, dim3(1), dim3(64), 0, st, tot, i, boot ? 1 : 0, G, gld, H, m, coef, sigma,
-                     launch_predicate_current());
+                     launch_predicate_current(), norm_flag);
 }
 
-void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma) {
-  hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(64), 0, st, tot, m, H, sigma, launch_predicate_current());
+void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma, const int *skip) {
+  hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(64), 0, st, tot, m, H, sigma, launch_predicate_current(), skip);
 }
 
 void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n) {

@@ -20,7 +20,7 @@ constexpr int kMaxRed = 2 * kMgsBlock - 1;  // partial-sum arrays per pass: dots
 constexpr int kFusedMaxM = 50;     // largest Krylov dimension served by the one-sweep Arnoldi step
 constexpr int kFusedNormSlot = kFusedMaxM;  // coefficient array: h_0..h_i, then ||u_i|| in this slot
 constexpr int kFusedCoef = kFusedMaxM + 2;
-constexpr int kFusedRed = 2 * kFusedMaxM + 4;  // partial-sum arrays of one fused sweep (upper bound)
+constexpr int kFusedRed = 2 * kFusedMaxM + 5;  // partial-sum arrays of one fused sweep (upper bound)
 
 // Five coefficient bands of a stencil operator on a rows x cols padded grid.
 struct Bands {
@@ -182,7 +182,7 @@ void set_split_from(int first_step);
 int get_split_from();
 // Step nv of a cycle: with the coefficients coef[0..nv] (already divided by sigma_k)
 // and coef[kFusedNormSlot] = sigma_nv, store the new vector
-// (A V_nv) / sigma_nv - sum_k coef[k] V_k in slot nv + 1 and the 2 nv + 4 partial sums
+// (A V_nv) / sigma_nv - sum_k coef[k] V_k in slot nv + 1 and the 2 nv + 5 partial sums
 // (see k_arnoldi_fused) in part.
 // has_halo: the grid rows in front of the first and behind the last row exist in the
 // halos of slots nv and nv + 1 (a neighbouring rank's rows, zeros beyond the mesh)
@@ -206,25 +206,42 @@ inline int64_t strip_major_size(int rows, int cols) {
 }
 // dst (strip-major) = src (grid order; src_has_halo_rows: with a grid row in front and behind, which are copied too)
 void launch_to_strips(hipStream_t st, const double *src, double *dst, int rows, int cols, bool src_has_halo_rows);
+// src / sqrt(sum(part)) in one pass, stored in grid order (grid_dst) and strip-major (strip_dst); *out = the norm
+void launch_scale_to_strips(hipStream_t st, const double *src, double *grid_dst, double *strip_dst, const double *part,
+                            int nparts, int rows, int cols, double *out);
 // launch_combine / launch_unscale for strip-major basis vectors; x and dst are in grid order
 void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
                            int cols, const int *count, bool accumulate, const double *sigma);
 void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols);
 bool fused_bands_splittable(int nv, int rows, int cols);
+// Whether the sweep of step nv delivers <t, t> as its last partial sum (2 nv + 5 sums instead of 2 nv + 4).
+bool fused_sweep_has_tt(int nv);
 // The update alone on the cnt unknowns from k0 on (n: unknowns of the local vector):
 // the new vector in slot nv + 1 and its squared norm in part.
 // map != nullptr: the basis vectors are strip-major.
+// skip != nullptr (here and in the two launchers below): a device flag; the kernel returns at once
+// when it is non-zero (the norm the closing step exists for was obtained from the last sweep's
+// sums, see launch_fused_coeffs).
 void launch_arnoldi_close(hipStream_t st, int nv, const Bands &b, const double *V, int64_t ld, const double *coef,
                           int64_t n, int cols, int64_t k0, int64_t cnt, bool has_halo, double *part, int *nparts,
-                          const StripMap *map = nullptr);
+                          const StripMap *map = nullptr, const int *skip = nullptr);
 // tot[q] = sum_i part[q * np + i], one workgroup per quantity
-void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot);
+void launch_reduce_parts_wide(hipStream_t st, const double *part, int nq, int np, double *tot,
+                              const int *skip = nullptr);
 // Coefficients of step i from the totals of the previous sweep (boot: of the operator
 // kernel applied to the stored, normalised v_i); see k_fused_coeffs.
+// norm_flag != nullptr (step m - 1, the one the closing kernel serves): also the norm of the vector
+// that step would produce, ||A v_i - sum_k h_k v_k||^2 = ||A v_i||^2 - sum_k h_k^2 (the identity
+// modified Gram-Schmidt satisfies link by link), from the previous sweep's <t, t>.  Where the
+// difference keeps at least 1/64 of ||A v_i||^2 the kernel stores its root in sigma[i + 1] and
+// H[i + 1][i] and sets *norm_flag = 1 (the closing kernel and what follows it then return at once);
+// otherwise (cancellation, or anything that is not finite) it sets *norm_flag = 0 and the closing
+// kernel forms the vector and takes its norm explicitly.
 void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, double *G, int gld, double *H,
-                         int m, double *coef, double *sigma);
+                         int m, double *coef, double *sigma, int *norm_flag = nullptr);
 // sigma[m] = sqrt(tot[0]), H[m][m-1] = sigma[m]
-void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma);
+void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma,
+                         const int *skip = nullptr);
 // dst = src / sigma[k]
 void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n);
 

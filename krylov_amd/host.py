@@ -210,6 +210,19 @@ class GMRESSolver:
         """Whether the basis of the last solve was stored strip by strip."""
         return bool(capi.lib().kry_gmres_basis_strip_major(self.h))
 
+    def set_norm_from_sums(self, on):
+        """H(m, m-1) from the last sweep's sums (default for a step object's solver) or from the closing pass."""
+        check(capi.lib().kry_gmres_set_norm_from_sums(self.h, int(bool(on))))
+
+    def get_norm_from_sums(self):
+        return bool(capi.lib().kry_gmres_get_norm_from_sums(self.h))
+
+    def last_norm_from_sums(self):
+        """Whether the last solve's final cycle took H(m, m-1) from sums (False: it formed the vector)."""
+        u = C.c_int()
+        check(capi.lib().kry_gmres_last_norm_from_sums(self.h, C.byref(u)))
+        return bool(u.value)
+
     def cycle_bytes(self, op):
         b = (C.c_double * capi.K_COUNT)()
         l = (C.c_int * capi.K_COUNT)()

@@ -97,24 +97,52 @@ ORC_API void orc_csr_matvec(double *res, const int64_t *rowptr,
   }
 }
 
+/* Yardstick build only (-DORC_EXACT_SUMS, libkrylov_oracle_exact.so): the two
+ * reductions below are summed pairwise in extended precision (64-bit
+ * significand, blocks of 128 products at the leaves), which bounds their
+ * rounding error by about 150 * 2^-64 of the sum of the magnitudes -- three
+ * orders of magnitude below any double-precision summation order.  It answers
+ * one question, "which of two double-precision runs is closer to exactly
+ * summed dot products", and is never the parity checker: the reference sums
+ * sequentially in double (include/matrix.hpp:35-52), as the default build does. */
+#ifdef ORC_EXACT_SUMS
+static long double orc_pairwise(const double *a, const double *b, long n) {
+  if (n <= 128) {
+    long double s = 0.0L;
+    for (long i = 0; i < n; i++) s += (long double)a[i] * (long double)b[i];
+    return s;
+  }
+  const long h = n / 2;
+  return orc_pairwise(a, b, h) + orc_pairwise(a + h, b + h, n - h);
+}
+#endif
+
 /* dot(real&, const vector&, const vector&), include/matrix.hpp:35-44 */
 ORC_API double orc_dot(const double *lhs, const double *rhs, long n) {
+#ifdef ORC_EXACT_SUMS
+  return (double)orc_pairwise(lhs, rhs, n);
+#else
   double acc = 0.0;
   ORC_PAR_SUM(acc)
   for (long i = 0; i < n; i++) {
     acc += lhs[i] * rhs[i];
   }
   return acc;
+#endif
 }
 
 /* l2_norm, include/matrix.hpp:46-52 */
 ORC_API double orc_l2_norm(const double *v, long n) {
+#ifdef ORC_EXACT_SUMS
+  return (double)sqrtl(orc_pairwise(v, v, n));
+#else
   double acc = 0.0;
   ORC_PAR_SUM(acc)
   for (long i = 0; i < n; i++) {
     acc += v[i] * v[i];
   }
   return sqrt(acc);
+#endif
 }
 
 /* normalize, include/matrix.hpp:54-60 (true division, not a reciprocal) */

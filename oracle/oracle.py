@@ -16,8 +16,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KRYLOV_ORACLE_OMP=1 selects the thread-parallel timing build (benchmark's all-cores
-# CPU baseline only; its reductions sum in a different order, so it is not a checker)
-_LIB_NAME = "libkrylov_oracle_omp.so" if os.environ.get("KRYLOV_ORACLE_OMP") else "libkrylov_oracle.so"
+# CPU baseline only; its reductions sum in a different order, so it is not a checker).
+# variant() below binds a second copy of this module to another build of the same source.
+_LIB_NAME = globals().get("_FORCED_LIB_NAME") or (
+    "libkrylov_oracle_omp.so" if os.environ.get("KRYLOV_ORACLE_OMP") else "libkrylov_oracle.so")
 _LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 _lib = None
 
@@ -26,6 +28,25 @@ _vp = C.c_void_p
 
 BOTTOM, TOP, LEFT, RIGHT = 0, 1, 2, 3
 FIELD_T, FIELD_U, FIELD_V = 0, 1, 2
+
+
+def variant(kind):
+    """A second instance of this module bound to another build of krylov_oracle.c:
+    "exact" = dot products and norms summed pairwise in extended precision (the
+    yardstick that tells which of two double-precision runs is closer to exactly
+    summed reductions; never the parity checker), "omp" = the thread-parallel
+    timing build."""
+    import importlib.util
+    import sys
+    name = "oracle_variant_" + kind
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
+    mod = importlib.util.module_from_spec(spec)
+    mod.__dict__["_FORCED_LIB_NAME"] = {"exact": "libkrylov_oracle_exact.so", "omp": "libkrylov_oracle_omp.so"}[kind]
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def build(force=False):

@@ -637,7 +637,7 @@ def test_recorded_reference_runs_first_steps(ctx, idx):
     for k in range(5):
         d = dev.timestep(run["dt"])
         want = run["max_delta"][str(k)]
-        assert abs(d - want) <= 1e-9 * abs(want), (k, d, want)
+        assert abs(d - want) <= RTOL * abs(want), (k, d, want)  # measured: at most 1.5e-12 (62 x 62, GMRES(30))
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -723,9 +723,10 @@ def test_timesteps_match_reference(ctx, oracle, name, make, shape, m, tdp):
         d = dev.timestep(0.25)
         if not (math.isfinite(dr) and dr < 1e100):
             break
-        assert abs(d - dr) <= 1e-8 * abs(dr), (step, d, dr)
-        assert rel(dev.delta(), ref.delta()) <= 1e-8
-        assert rel(dev.field(0)[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]) <= 1e-8
+        # measured: at most 3e-14 (the reduced normal equations of these cases have condition numbers up to 1.4e3)
+        assert abs(d - dr) <= RTOL * abs(dr), (step, d, dr)
+        assert rel(dev.delta(), ref.delta()) <= RTOL
+        assert rel(dev.field(0)[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]) <= RTOL
         assert dev.cur_time() == ref.cur_time()
     # ghost cells of the velocity fields follow the moving boundary values exactly
     for f in (1, 2):
@@ -911,7 +912,7 @@ def test_random_configurations(ctx, oracle, seed):
         assert np.array_equal(dev.dense_system(), ref.dense_system())
     for _ in range(3):
         d, dr = dev.timestep(dt), ref.timestep(dt)
-        assert abs(d - dr) <= 1e-9 * abs(dr) + 1e-13
+        assert abs(d - dr) <= RTOL * abs(dr) + 1e-13  # measured: at most 2e-13 relative
     T, Tr = dev.field(0)[1:-1, 1:-1], ref.field(0)[1:-1, 1:-1]
-    assert rel(T, Tr) <= 1e-9
+    assert rel(T, Tr) <= RTOL
     assert dev.cur_time() == ref.cur_time()
