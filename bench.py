@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--cpu-m", type=int, default=12, help="Arnoldi steps of the CPU sample cycle")
     ap.add_argument("--cpu-mesh", type=int, default=0, help="mesh of the CPU sample (0: same as --mesh)")
     ap.add_argument("--cpu-sample-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -87,6 +88,12 @@ def cpu_baseline(mesh, m_sample, dt):
                   % (mesh, mesh, m_sample, m_sample - 1, " -fopenmp (vector loops parallel)" if omp else "", threads,
                      "" if threads == 1 else "s", el),
         "seconds": el, "nominal_gbps": nominal / el / 1e9,
+        # the sample above is cut to the cheapest Arnoldi steps so that the default run stays short; the uncut
+        # cycle of this port was timed by the full-size parity test of the same workload
+        "full_cycle_reference": {"value": 50 / 95.0, "unit": "iters/s", "cores": 1,
+                                 "source": "tests/test_gpu_full_size.py (config 3: 8192x8192, one implicit step with the "
+                                           "full GMRES(50) cycle) takes 95 s on the GPU box's host: recorded there, "
+                                           "not measured in this run"} if (mesh == 8192 and not omp) else None,
     }
 
 
@@ -110,6 +117,39 @@ def cpu_baseline_all_cores(mesh, m_sample, dt):
         return {"error": repr(e)}
 
 
+def supervise_ranks(args):
+    """bench.py as one rank of a multi-GPU job: the work runs in a child process (started before this process
+    touches a GPU), so that a rank that hangs or dies -- the multi-GPU transports have never run on more than one
+    physical GPU before -- can be replaced by a fresh process with a more conservative configuration.  Every rank's
+    supervisor takes the same decisions: a failure on one rank ends the others through their watchdogs
+    (krylov_amd.dist_bench.Watchdog, exit code 3).  Retries rendezvous through a file store of their own, since the
+    launcher's store still holds the keys of the failed attempt."""
+    import subprocess
+    import tempfile
+    levels = [
+        {},                                                                       # as configured
+        {"KRY_DIST_GRAPH": "0"},                                                  # eager launches only
+        {"KRY_DIST_GRAPH": "0", "KRY_DIST_COMM": "torch", "KRY_HALO_OVERLAP": "0"},  # torch.distributed callbacks
+    ]
+    job = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"))
+    rank = int(os.environ.get("RANK", "0"))
+    rc = 1
+    for attempt, extra in enumerate(levels):
+        env = dict(os.environ, KRY_DIST_ATTEMPT=str(attempt), **extra)
+        if attempt > 0:
+            env["KRY_DIST_INIT_METHOD"] = "file://" + os.path.join(tempfile.gettempdir(), "kry_rdzv_%s_%d" % (job, attempt))
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--dist-child"]
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0:
+            return 0
+        if rank == 0:
+            print("bench.py: attempt %d of the %d-rank run ended with exit code %d%s" %
+                  (attempt, int(os.environ.get("WORLD_SIZE", "1")), rc,
+                   "; starting the ranks again with %r" % levels[attempt + 1] if attempt + 1 < len(levels) else ""),
+                  file=sys.stderr, flush=True)
+    return rc
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout.  Libraries underneath (RCCL
     prints a version banner when its first communicator comes up) write to
@@ -119,6 +159,11 @@ def claim_stdout():
     real = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     return real
+
+
+def dist_bench_label():
+    from krylov_amd import dist_bench
+    return dist_bench.sweep_kernel_label()
 
 
 def main():
@@ -137,6 +182,8 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29541"),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    if world > 1 and not args.dist_child:
+        sys.exit(supervise_ranks(args))
     out_stream = claim_stdout()
     if world > 1:
         from krylov_amd import dist_bench
@@ -216,11 +263,10 @@ def main():
         "mgs_block_full": "k_mgs_block<%d,%d> (Gram-Schmidt sweep: %d projections applied + %d dots)",
         "mgs_block_part": "k_mgs_block<%d,kc> (Gram-Schmidt sweep: %d projections applied + kc < %d dots)",
         "mgs_last": "k_mgs_block<kp,0> (closing Gram-Schmidt sweep of an Arnoldi step: kp <= %d projections applied + norm)",
-        "arnoldi_fused": "k_arnoldi_fused<i> / k_arnoldi_split<i> (one-sweep Arnoldi step, 256 threads per workgroup up to "
-                         "i = 13, 512 threads whose halves split the basis vectors above: operator applied to the newest basis vector, "
+        "arnoldi_fused": dist_bench_label() + ": operator applied to the newest basis vector, "
                          "orthogonalised against v_0..v_i, operator applied to the result for all dot products of the "
                          "next step; reads i+1 vectors and the operator -- five bands, or with generated bands the two velocity "
-                         "arrays their interior entries are evaluated from --, writes one vector)",
+                         "arrays their interior entries are evaluated from --, writes one vector",
     }
     timed = {n: k for n, k in kernels.items() if n in families and k["gbps"]}
     if timed and not ext_stats:

@@ -240,6 +240,8 @@ int kry_gmres_last_norm_from_sums(kry_gmres *g, int *used);
  * env KRY_SPLIT_FROM), values below 12 mean 12, values beyond the last step: never.
  * Returns the value in effect. */
 int kry_set_one_sweep_split(int first_step);
+/* The range of steps in effect for the 512-thread form: first and last step of a cycle it serves. */
+int kry_get_one_sweep_split(int *first_step, int *last_step);
 int64_t kry_gmres_size(const kry_gmres *g);
 int kry_gmres_iterations(const kry_gmres *g);
 /* KRY_GMRES_EXTENDED only; no counterpart in the reference, whose solve always

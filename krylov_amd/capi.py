@@ -77,6 +77,7 @@ SIGNATURES = {
     "kry_gmres_size": (C.c_int64, [_vp]),
     "kry_gmres_iterations": (C.c_int, [_vp]),
     "kry_set_one_sweep_split": (C.c_int, [C.c_int]),
+    "kry_get_one_sweep_split": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kry_gmres_cycle_bytes": (C.c_int, [_vp, _vp, _dp, C.POINTER(C.c_int)]),
     "kry_ie_create": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                 _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double,

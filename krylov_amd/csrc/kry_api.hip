@@ -1026,6 +1026,12 @@ int kry_set_one_sweep_split(int first_step) {
   return get_split_from();
 }
 
+int kry_get_one_sweep_split(int *first_step, int *last_step) {
+  if (first_step) *first_step = get_split_from();
+  if (last_step) *last_step = get_split_upto();
+  return KRY_OK;
+}
+
 // The hand-over step in effect.  The first sweep recovers its coefficients from the Gram
 // matrix of ALL vectors stored so far, and the chain only carries the Gram entries of
 // vectors that share a group of kblock links: the hand-over happens while the basis is
@@ -1326,6 +1332,18 @@ static void launch_close_whole(kry_gmres *g, kry_op *op, int *np, const int *ski
                        g->ctx->nranks > 1, g->fparts, np, g->strips ? &smap : nullptr, skip);
 }
 
+// First step of a cycle whose sweep reads the stored bands although it could evaluate them (experimentation
+// knob, env KRY_STORED_FROM; default: never).
+static int stored_bands_from() {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) {
+    r = getenv("KRY_STORED_FROM") ? atoi(getenv("KRY_STORED_FROM")) : 1000;
+    v.store(r, std::memory_order_relaxed);
+  }
+  return r;
+}
+
 // Totals of nq quantities from the partial sums of a one-sweep kernel, summed over the ranks.
 static int fused_totals(kry_gmres *g, int nq, int np, const int *skip = nullptr) {
   launch_reduce_parts_wide(g->ctx->stream, g->fparts, nq, np, g->ftot, skip);
@@ -1382,6 +1400,7 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
         }
       }
       const BandGen *gen = g->strips ? &op->gen_strips : (op->has_gen && op->use_gen ? &op->gen : nullptr);
+      if (i >= stored_bands_from()) gen = nullptr;
       if (ranks && g->overlap_halo && fused_bands_splittable(i, op->rows, op->cols)) {
         // The neighbours' rows of the new vector travel on the second stream while the bands of
         // rows that do not touch them are swept; the first and the last band follow.

@@ -239,7 +239,8 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
 // next round consumes the values: each value is consumed and the request for its
 // successor issued in the same place, and the wait for any one of them leaves all
 // younger requests in flight.
-template <int NV, bool GEN>
+// S: register sets for the requested values; the requests run S - 1 rows ahead of the row being worked on.
+template <int NV, bool GEN, int S = 2>
 __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b, BandGen gen,
                                                           const double *__restrict__ V, int64_t ld,
                                                           const double *__restrict__ u_in,
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };     // ... or a halo row
   // position of this lane's column (and of its two neighbours) in a row of a basis vector or
   // velocity snapshot, and the distance between rows
-  const bool sm = GEN && geo.sm != 0;
+  const bool sm = geo.sm != 0;
   const int pitch = sm ? kBlock : P;
   int off = cc, offm = ccm, offp = ccp, soff = cc;
   if (sm) {
@@ -317,16 +318,19 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   }
 
   const double gdiag = GEN ? gdiag_of(gen) : 0.0;
-  // The values requested for a round.  Two sets take turns (the loop below is unrolled
-  // by two): a value requested into the registers the next round reads needs no copy at
-  // the end of the round, which would have to wait for it.
+  // The values requested for a round.  S sets take turns (the loop below is unrolled S
+  // times): a value requested into the registers a later round reads needs no copy at
+  // the end of the round, which would have to wait for it.  The round that works on row
+  // rr requests row rr + S - 1 into the set the round before it has finished with.
+  static_assert(S >= 2 && S <= 4, "two to four register sets");
+  constexpr int D = S - 1;
   struct Req {
     double v[NV > 0 ? NV : 1];  // s_0 .. s_{NV-1}
     double b[5];                // five band entries, or (GEN) the two velocities next to the cell in its row
     double gu;                  // GEN: the velocity one row further
     double s, uh;               // s_NV two rows further; a neighbouring rank's row of the new vector
   };
-  Req qa, qb;
+  Req qa, qb, qc, qd;
   double gu0 = 0.0, gu1 = 0.0;  // GEN: velocity of rows rr - 1 and rr
   const bool yin = GEN && c >= 1 && c <= gen.cy;
   auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {  // what the operator coefficients of row r are made of
@@ -354,13 +358,16 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * pitch + off]);
     gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * pitch + off]);
   }
-  issue_op(qa, rs - 1);
-  {
-    const int64_t i0 = rowc(rs - 1) * pitch + off;
+  auto issue_all = [&](Req &n, int r) __attribute__((always_inline)) {  // everything the round of row r consumes
+    issue_op(n, r);
+    const int64_t i0 = rowc(r) * pitch + off;
 #pragma unroll
-    for (int k = 0; k < NV; k++) qa.v[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i0]);
-  }
-  issue_tail(qa, rs - 1);
+    for (int k = 0; k < NV; k++) n.v[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + i0]);
+    issue_tail(n, r);
+  };
+  issue_all(qa, rs - 1);
+  if (D > 1) issue_all(qb, rs);
+  if (D > 2) issue_all(qc, rs + 1);
   double bp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // operator coefficients of the previous row
   int p0 = rs;  // first row of the new vector not stored yet (the same in every lane of a wavefront)
   uint32_t deadline = geo.tick > 0 ? first_deadline(geo.tick) : 0u;
@@ -370,11 +377,11 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
-  // one round: consumes the values of set o (row rr), requests those of row rr + 1 into set n
+  // one round: consumes the values of set o (row rr), requests those of row rr + D into set n
   auto round = [&](const int rr, Req &o, Req &n) __attribute__((always_inline)) {
     const bool rowvalid = rr >= 0 && rr < rows;
     const bool active = rowvalid && ucol;
-    const int64_t idxn = rowc(rr + 1) * pitch + off;
+    const int64_t idxn = rowc(rr + D) * pitch + off;
     const int q = rr - 1;  // the row whose operator application (to the new vector) completes in this round
     const bool emit = q >= rs && colowned;
     // operator coefficients of row rr
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       const double gum = gu0, gup = o.gu;
       gu0 = gu1;
       gu1 = gup;
-      issue_op(n, rr + 1);
+      issue_op(n, rr + D);
       const int ip = gen.row0 + rr;
       const bool xin = ip >= 1 && ip <= gen.cx;
       // SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1, include/space_disc.hpp:83-113, as k_offdiag forms them
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     } else {
 #pragma unroll
       for (int j = 0; j < 5; j++) bc[j] = o.b[j];
-      issue_op(n, rr + 1);
+      issue_op(n, rr + D);
     }
     const int sl = (rr - rs + 2) & 3;  // sring slot of row rr
     const double *s0 = sring + sl * kBlock;
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     } else {
       u = opaque(u - lane_value(hpack, NV) * vi);
     }
-    issue_tail(n, rr + 1);
+    issue_tail(n, rr + D);
     // outside the columns and rows evaluated here: zero, or a neighbouring rank's row of the new vector
     u = active ? u : ((u_halo != nullptr && !rowvalid && cin) ? o.uh : 0.0);
     const int slot = (rr - rs + 1) & (kRing - 1);
@@ -484,10 +491,26 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 #pragma unroll
     for (int j = 0; j < 5; j++) bp[j] = bc[j];
   };
-  for (int rr = rs - 1; rr <= re; rr += 2) {
-    round(rr, qa, qb);
-    if (rr + 1 > re) break;
-    round(rr + 1, qb, qa);
+  for (int rr = rs - 1; rr <= re; rr += S) {
+    if (S == 2) {
+      round(rr, qa, qb);
+      if (rr + 1 > re) break;
+      round(rr + 1, qb, qa);
+    } else if (S == 3) {
+      round(rr, qa, qc);
+      if (rr + 1 > re) break;
+      round(rr + 1, qb, qa);
+      if (rr + 2 > re) break;
+      round(rr + 2, qc, qb);
+    } else {
+      round(rr, qa, qd);
+      if (rr + 1 > re) break;
+      round(rr + 1, qb, qa);
+      if (rr + 2 > re) break;
+      round(rr + 2, qc, qb);
+      if (rr + 3 > re) break;
+      round(rr + 3, qd, qc);
+    }
   }
   reduce_store_multi<NQ>(acc, red, part, band * geo.nstrips + strip, geo.nstrips * geo.nbands);
 }
@@ -560,7 +583,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   auto rowc = [&](int r) -> int64_t { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); };
   auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };
   // positions within a row of a basis vector / velocity snapshot, as in k_arnoldi_fused
-  const bool sm = GEN && geo.sm != 0;
+  const bool sm = geo.sm != 0;
   const int pitch = sm ? kBlock : P;
   int off = cc, offm = ccm, offp = ccp, soff = cc;
   if (sm) {
@@ -999,9 +1022,11 @@ __global__ __launch_bounds__(kBlock) void k_scale_to_strips(const double *__rest
   }
 }
 
-// x (grid order) = sum_k y_k V_k of strip-major vectors; per element the operations of k_combine.  Lanes move
-// 16 bytes: 128 of them cover the 256 positions of a strip's row (one aligned 2 KB line per vector), so the two
-// halves of a workgroup take two consecutive rows of a strip at a time.
+// x (grid order) = sum_k y_k V_k of strip-major vectors; per element the operations of k_combine.  A
+// workgroup takes one row of one strip at a time (lane = position in the row), so every read is one
+// aligned 2 KB line.  (Lanes that move 16 bytes, two rows per workgroup, were measured slower: 5.62
+// against 5.39 ms on an 8192 x 8192 grid with 50 vectors.)
+template <int U>
 __global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restrict__ V, int64_t ld,
                                                             const double *__restrict__ y, int m,
                                                             double *__restrict__ x, int rows, int P,
@@ -1014,27 +1039,19 @@ __global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restr
   }
   for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = sigma != nullptr ? y[i] / sigma[i] : y[i];
   __syncthreads();
-  const int half = threadIdx.x >> 7, lt = (threadIdx.x & 127) * 2;  // this lane's positions: lt and lt + 1
-  const int pairs = (rows + 1) / 2;
-  const int64_t total = (int64_t)map.nstrips * pairs;
+  const int lt = threadIdx.x;
+  const int64_t total = (int64_t)map.nstrips * rows;
   for (int64_t q = blockIdx.x; q < total; q += gridDim.x) {
-    const int s = (int)(q / pairs), r = (int)(q % pairs) * 2 + half;
+    const int s = (int)(q / rows), r = (int)(q % rows);
     const int c = s * map.W - 2 + lt;
     const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
-    // the strip's own columns only
-    const bool own0 = lt >= 2 && lt < wown + 2, own1 = lt + 1 >= 2 && lt + 1 < wown + 2;
-    if (r >= rows || !(own0 || own1)) continue;
+    if (lt < 2 || lt >= wown + 2) continue;  // the strip's own columns only
     const int64_t e = (int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt;
     const int64_t i = (int64_t)r * P + c;
-    double a0 = (accumulate && own0) ? x[i] : 0.0, a1 = (accumulate && own1) ? x[i + 1] : 0.0;
-#pragma unroll 8
-    for (int k = 0; k < m; k++) {
-      const d2 v = ld_nt(reinterpret_cast<const d2 *>(&V[(int64_t)k * ld + e]));
-      a0 = a0 + ys[k] * v.x;
-      a1 = a1 + ys[k] * v.y;
-    }
-    if (own0) __builtin_nontemporal_store(a0, &x[i]);
-    if (own1) __builtin_nontemporal_store(a1, &x[i + 1]);
+    double acc = accumulate ? x[i] : 0.0;
+#pragma unroll U
+    for (int k = 0; k < m; k++) acc = acc + ys[k] * __builtin_nontemporal_load(&V[(int64_t)k * ld + e]);
+    __builtin_nontemporal_store(acc, &x[i]);
   }
 }
 
@@ -1148,13 +1165,47 @@ int store_tick(int nv) {
   if (p >= 0) return nv >= from.load(std::memory_order_relaxed) ? p : 0;
   return nv <= 3 ? 0 : (nv <= 7 ? 2048 : (nv <= 12 ? 3072 : (nv <= 18 ? 4096 : (nv <= 27 ? 6144 : 8192))));
 }
+// Register sets of the 256-thread kernel for step nv (its requests run sets - 1 rows ahead).  Sweeps over few
+// vectors have few requests per row and registers to spare: more rows in flight.  Env KRY_FUSED_SETS=s0,s1,...
+// (one number per step from 0 on, 2 to 4) overrides; steps beyond kDeepSetsUpto always use two.
+constexpr int kDeepSetsUpto = 17;
+int fused_sets(int nv) {
+  static std::atomic<int> table[kDeepSetsUpto + 1];
+  static std::atomic<int> ready{0};
+  if (!ready.load(std::memory_order_acquire)) {
+    for (int i = 0; i <= kDeepSetsUpto; i++) table[i].store(2, std::memory_order_relaxed);
+    if (const char *e = getenv("KRY_FUSED_SETS")) {
+      int i = 0;
+      for (const char *p = e; *p && i <= kDeepSetsUpto; i++) {
+        int v = atoi(p);
+        table[i].store(v < 2 ? 2 : (v > 4 ? 4 : v), std::memory_order_relaxed);
+        p = strchr(p, ',');
+        if (!p) break;
+        p++;
+      }
+    }
+    ready.store(1, std::memory_order_release);
+  }
+  return nv >= 0 && nv <= kDeepSetsUpto ? table[nv].load(std::memory_order_relaxed) : 2;
+}
+
+// Workgroups of the 256-thread kernel for step nv that a compute unit holds at once (registers and LDS),
+// asked of the runtime once per step; 0 until then.
+std::atomic<int> g_resident[kFusedMaxM];
+int fused_resident_query(int nv);  // below, behind the kernel table
+
 FusedGeom fused_geom(int rows, int P, int nv) {
   FusedGeom g;
   g.rows = rows;
   g.P = P;
   g.nstrips = (P + kStripMax - 1) / kStripMax;
   g.W = (P + g.nstrips - 1) / g.nstrips;
-  const int cap = 256 * (nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv < kSplitFrom ? 2 : 1)));
+  int per_cu = nv <= 5 ? 4 : (nv <= 10 ? 3 : (nv < kSplitFrom ? 2 : 1));
+  if (nv <= kDeepSetsUpto && fused_sets(nv) > 2) {
+    const int q = fused_resident_query(nv);
+    if (q >= 1 && q <= 4) per_cu = q;
+  }
+  const int cap = 256 * per_cu;
   int best_nb = 1;
   double best = -1.0;
   // `slots` workgroups run at a time, `r` rounds of them
@@ -1181,13 +1232,46 @@ FusedGeom fused_geom(int rows, int P, int nv) {
   return g;
 }
 
+template <int NV>
+constexpr size_t fused_lds() {
+  return sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 5) * (kBlock / 64));
+}
+
+// the 256-thread kernel with S register sets
+template <int NV, bool GEN, int S>
+void launch_fused_sets(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
+                       int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
+                       const double *u_halo, int s_halo, int launch_bands) {
+  constexpr size_t lds = fused_lds<NV>();
+  static std::atomic<uint64_t> configured{0};
+  allow_lds(&k_arnoldi_fused<NV, GEN, S>, lds, configured, "LDS size of the one-sweep kernel");
+  hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN, S>), dim3(geo.nstrips * launch_bands), dim3(kBlock), lds, st, geo, b, gen, V,
+                     ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
+}
+
+template <int NV, int S>
+int resident_t() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_arnoldi_fused<NV, true, S>, kBlock, fused_lds<NV>()) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 template <int NV, bool GEN>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
                     int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
                     const double *u_halo, int s_halo, int launch_bands) {
-  constexpr size_t lds =
-      sizeof(double) * ((size_t)(NV + 1) * kBlock + (store_rows(NV) + 4) * kBlock + (2 * NV + 5) * (kBlock / 64));
+  constexpr size_t lds = fused_lds<NV>();
   static_assert(lds <= 160 * 1024, "LDS of one compute unit");
+  if constexpr (GEN && NV <= kDeepSetsUpto) {
+    const int sets = fused_sets(NV);
+    if (sets == 3)
+      return launch_fused_sets<NV, GEN, 3>(st, geo, b, gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_bands);
+    if (sets == 4)
+      return launch_fused_sets<NV, GEN, 4>(st, geo, b, gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_bands);
+  }
   static std::atomic<uint64_t> configured{0};
   allow_lds(&k_arnoldi_fused<NV, GEN>, lds, configured, "LDS size of the one-sweep kernel");
   // (with stored bands the 512-thread kernel needs scratch from 47 earlier vectors on and is slower there)
@@ -1250,6 +1334,12 @@ struct FusedTable {
     else
       FusedTable<NV - 1>::close(nv, st, a);
   }
+  static int resident(int nv, int sets) {
+    if constexpr (NV <= kDeepSetsUpto) {
+      if (nv == NV) return sets == 4 ? resident_t<NV, 4>() : (sets == 3 ? resident_t<NV, 3>() : resident_t<NV, 2>());
+    }
+    return FusedTable<NV - 1>::resident(nv, sets);
+  }
 };
 
 template <>
@@ -1257,11 +1347,24 @@ struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const BandGen *, const double *, int64_t,
                     const double *, double *, bool, int, int) {}
   static void close(int, hipStream_t, const CloseArgs &) {}
+  static int resident(int, int) { return 0; }
 };
+
+int fused_resident_query(int nv) {
+  int r = g_resident[nv].load(std::memory_order_relaxed);
+  if (r == 0) {
+    r = FusedTable<>::resident(nv, fused_sets(nv));
+    if (r < 1) r = -1;  // the runtime would not say: keep the rule of thumb
+    g_resident[nv].store(r, std::memory_order_relaxed);
+  }
+  return r;
+}
 
 }  // namespace
 
 bool fused_sweep_has_tt(int nv) { return sweep_has_tt(nv); }
+
+int get_split_upto() { return split_upto(); }
 
 void set_split_from(int first_step) { g_split_from.store(first_step < 0 ? kSplitFrom : first_step); }
 int get_split_from() { return split_from(); }
@@ -1303,10 +1406,20 @@ void launch_scale_to_strips(hipStream_t st, const double *src, double *grid_dst,
 void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
                            int cols, const int *count, bool accumulate, const double *sigma) {
   const StripMap map = strip_map(rows, cols);
-  const int64_t total = (int64_t)map.nstrips * ((rows + 1) / 2);
+  const int64_t total = (int64_t)map.nstrips * rows;
   // 1024 workgroups: four per compute unit, each walking a share of the (strip, row) pairs
-  hipLaunchKernelGGL(k_combine_strips, dim3((unsigned)(total < 1024 ? total : 1024)), dim3(kBlock), 0, st, V, ld, y, m, x, rows,
-                     cols, count, accumulate ? 1 : 0, sigma, map);
+  static const int grid_env = getenv("KRY_COMBINE_GRID") ? atoi(getenv("KRY_COMBINE_GRID")) : 1024;
+  static const int unroll_env = getenv("KRY_COMBINE_UNROLL") ? atoi(getenv("KRY_COMBINE_UNROLL")) : 8;
+  const unsigned grid = (unsigned)(total < grid_env ? total : grid_env);
+  if (unroll_env >= 16)
+    hipLaunchKernelGGL(k_combine_strips<16>, dim3(grid), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
+                       accumulate ? 1 : 0, sigma, map);
+  else if (unroll_env <= 4)
+    hipLaunchKernelGGL(k_combine_strips<4>, dim3(grid), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
+                       accumulate ? 1 : 0, sigma, map);
+  else
+    hipLaunchKernelGGL(k_combine_strips<8>, dim3(grid), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
+                       accumulate ? 1 : 0, sigma, map);
 }
 
 void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols) {
@@ -1319,7 +1432,7 @@ void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Band
                           const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen, int which,
                           bool strip_major) {
   FusedGeom g = fused_geom(rows, cols, nv);
-  if (strip_major && gen != nullptr) {
+  if (strip_major) {
     g.sm = 1;
     g.SB = (rows + 2) * kBlock;
   }

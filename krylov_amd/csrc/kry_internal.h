@@ -180,6 +180,7 @@ int fused_parts(int rows, int cols);
 // First step of a cycle that the 512-thread variant of the sweep serves (process-wide; < 0: the default).
 void set_split_from(int first_step);
 int get_split_from();
+int get_split_upto();  // last step served by it
 // Step nv of a cycle: with the coefficients coef[0..nv] (already divided by sigma_k)
 // and coef[kFusedNormSlot] = sigma_nv, store the new vector
 // (A V_nv) / sigma_nv - sum_k coef[k] V_k in slot nv + 1 and the 2 nv + 5 partial sums

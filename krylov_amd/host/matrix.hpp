@@ -3,8 +3,10 @@
 #ifndef KRYLOV_HOST_MATRIX_HPP_
 #define KRYLOV_HOST_MATRIX_HPP_
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <numeric>
 
 #include "constants.hpp"
 #include "device.hpp"
@@ -33,24 +35,21 @@ inline vector &dot(vector &result, const matrix &lhs, const vector &rhs) {
   return result;
 }
 
-// include/matrix.hpp:35-44
+// The three vector helpers of include/matrix.hpp:35-60, stated with the standard
+// algorithms.  Their semantics are what the reference's loops define: a strictly
+// sequential left-to-right sum starting from 0.0 (std::inner_product evaluates
+// acc = acc + a * b in order), and normalisation by true division.
 inline real dot(real &result, const vector &lhs, const vector &rhs) noexcept {
-  result = 0.0;
-  for (unsigned long i = 0; i < lhs.shape()[0]; i++) result += lhs(i) * rhs(i);
-  return result;
+  // the reference bounds its loop by the left operand's length
+  return result = std::inner_product(lhs.begin(), lhs.end(), rhs.begin(), real(0.0));
 }
 
-// include/matrix.hpp:46-60
-inline real l2_norm(const vector &v) noexcept {
-  real l2 = 0.0;
-  for (real c : v) l2 += c * c;
-  return std::sqrt(l2);
-}
+inline real l2_norm(const vector &v) noexcept { return std::sqrt(std::inner_product(v.begin(), v.end(), v.begin(), real(0.0))); }
 
 inline real normalize(vector &v) noexcept {
-  const real l2 = l2_norm(v);
-  for (real &r : v) r /= l2;
-  return l2;
+  const real length = l2_norm(v);
+  std::transform(v.begin(), v.end(), v.begin(), [length](real entry) { return entry / length; });
+  return length;
 }
 
 #endif  // KRYLOV_HOST_MATRIX_HPP_

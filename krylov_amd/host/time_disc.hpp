@@ -8,6 +8,7 @@
 #include <exception>
 #include <functional>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -167,7 +168,27 @@ protected:
   real staged_time_ = 0.0;
 };
 
+namespace krylov {
+// Whether a solver type carries what the device step needs to know about it.
+template <typename S, typename = void> struct is_device_solver : std::false_type {};
+template <typename S>
+struct is_device_solver<S, std::void_t<decltype(S::iterations), decltype(S::device_flags)>> : std::true_type {};
+}  // namespace krylov
+
+// The reference composes ImplicitEuler<SpaceDisc_, Solver_> from ANY pair of types with the right members
+// (include/time_disc.hpp:190-191: the solver through Solver_(n), solve(), prev_result(), :234, :280, :380; the
+// discretisation through Dx_*/Dy_*/flux_integral/source_fd, :268-302).  The device step is narrower, and says so
+// at compile time instead of silently computing something else: the physics on the device is that of
+// SecondOrderCentered (only its four parameters travel to the device), and the solver is one of the device
+// solvers (GMRESSolver<m>, GMRESTDPSolver<m>), which tell the device object their cycle length and kind.
 template <typename SpaceDisc_, typename Solver_> class ImplicitEuler : public TimeDisc<SpaceDisc_> {
+  static_assert(std::is_same<SpaceDisc_, SecondOrderCentered>::value,
+                "ImplicitEuler<SpaceDisc_, Solver_> (reference seam include/time_disc.hpp:190-191): the device step "
+                "implements the assembly of SecondOrderCentered only; another SpaceDisc_ would be ignored");
+  static_assert(krylov::is_device_solver<Solver_>::value,
+                "ImplicitEuler<SpaceDisc_, Solver_> (reference seam include/time_disc.hpp:190-191): Solver_ must be a "
+                "device solver providing `iterations` and `device_flags` (GMRESSolver<m> or GMRESTDPSolver<m>)");
+
 public:
   using Solver = Solver_;
   using SpaceDisc = SpaceDisc_;
@@ -189,13 +210,22 @@ public:
   // functions are sampled for the time the NEXT step will start from (they
   // depend on position and time only); for Python callables that is the
   // expensive host part of a step, and it is hidden behind the device work.
+  // If a boundary function throws while the queued step runs, the step itself is still waited for (its
+  // result is dropped, the returned value is NaN), and nothing stays staged for the new time: the next
+  // timestep() samples the boundary values again before it queues anything.
   real timestep(const real dt) noexcept {
     return this->guarded_step([&]() -> real {
       this->push_bc_values();
       krylov::check(kry_ie_timestep_async(this->ie_, dt), "kry_ie_timestep_async");
       const real t_next = this->cur_time();
-      this->sample_bc_values(t_next, this->bc_scratch_);
       real max_delta = 0.0;
+      try {
+        this->sample_bc_values(t_next, this->bc_scratch_);
+      } catch (...) {
+        (void)kry_ie_last_max_delta(this->ie_, &max_delta);  // drain the step that is in flight
+        this->staged_ = false;
+        throw;
+      }
       krylov::check(kry_ie_last_max_delta(this->ie_, &max_delta), "kry_ie_last_max_delta");
       this->stage_bc_values(this->bc_scratch_, t_next);
       return max_delta;

@@ -122,6 +122,8 @@ def jobs(oracle):
     a = EXT_ANISO
     J.submit("ext_aniso", lambda: cpu_steps(oracle, problems.s_aniso(a["n"]), a["m"], True,
                                             extended=(a["rtol"], a["max_cycles"])), 16)
+    J.submit("ext_aniso_exact", lambda: cpu_steps(exact, problems.s_aniso(a["n"]), a["m"], True,
+                                                  extended=(a["rtol"], a["max_cycles"])), 16)
     J.submit("cfg5", lambda: cpu_steps(oracle, problems.s_aniso(8192), 10, True, steps=3), 14)
     return J
 
@@ -250,7 +252,10 @@ def test_config5_8192_s_aniso_line_preconditioner_vs_cpu(ctx, jobs, capfd):
     check(res, h_cols=1)
 
 
-def check_extended(capfd, label, dev, ref, spec, cpu_s):
+def check_extended(capfd, label, dev, ref, spec, cpu_s, exact=None):
+    """exact: the same run of the yardstick build (dot products summed exactly).  Where the reference-order
+    run itself sits near 1e-10 from it, the device is held to 1e-10 of the yardstick and to being no farther
+    from the reference-order run than that run is from the yardstick."""
     it, cy, cv, rr = dev["stats"]
     it_ref, cy_ref, cv_ref, rr_ref = ref["stats"]
     res = errors(dev, ref)
@@ -264,6 +269,16 @@ def check_extended(capfd, label, dev, ref, spec, cpu_s):
     # residual estimates differ in the last digits and one of them may sit on the tolerance) they are
     # two different iterates that both meet the tolerance.
     bar = RTOL if it == it_ref else 50.0 * spec["rtol"]
+    if exact is not None and exact["stats"][0] == it == it_ref:
+        res_exact, ref_exact = errors(dev, exact), errors(ref, exact)
+        say(capfd, "[%s] device against exactly summed dot products: max|delta| %.2e, delta %.2e, T %.2e; reference order "
+            "against them: max|delta| %.2e, delta %.2e, T %.2e" % (label, res_exact["max_delta"], res_exact["delta"],
+                                                                    res_exact["T"], ref_exact["max_delta"], ref_exact["delta"],
+                                                                    ref_exact["T"]))
+        for key in ("delta", "T", "max_delta"):
+            assert res_exact[key] <= RTOL, key
+            assert res[key] <= max(bar, 1.05 * ref_exact[key] + 1e-12), key
+        return
     assert res["delta"] <= bar and res["T"] <= bar and res["max_delta"] <= bar
 
 
@@ -288,5 +303,6 @@ def test_restarted_solver_8192_s_aniso_line_preconditioner_vs_cpu(ctx, jobs, cap
     dev = device_steps(ctx, problems.s_aniso(a["n"]), a["m"], True, extended=(a["rtol"], a["max_cycles"]))
     ref, cpu_s = jobs.result("ext_aniso", capfd)
     assert dev["stats"][1] >= 2  # the restart is part of what is tested
+    exact, _ = jobs.result("ext_aniso_exact", capfd)
     check_extended(capfd, "restarted GMRES(%d) + line preconditioner, 8192^2 S-aniso to %g" % (a["m"], a["rtol"]), dev, ref, a,
-                   cpu_s)
+                   cpu_s, exact)

@@ -258,14 +258,14 @@ def test_time_dependent_python_callables_through_the_module(krylov, oracle, name
         d, dr = sim.timestep(0.25), ref.timestep(0.25)
         if not (math.isfinite(dr) and dr < 1e100):
             break
-        assert abs(d - dr) <= 1e-8 * abs(dr), (step, d, dr)
+        assert abs(d - dr) <= 1e-10 * abs(dr), (step, d, dr)
         assert sim.cur_time() == ref.cur_time() == 0.25 * (step + 1)
     assert not sim.failed() and sim.last_error() == ""
     # twelve functions sampled once per step (one sample ahead), on 2 (cx + cy) boundary cells each
     assert calls["n"] - n0 == 6 * 3 * 2 * (24 + 16)
     mesh = sim.mesh()
     T, Tr = mesh.Temp_array(), ref.field(0)
-    assert float(np.linalg.norm(T[1:-1, 1:-1] - Tr[1:-1, 1:-1]) / np.linalg.norm(Tr[1:-1, 1:-1])) <= 1e-8
+    assert float(np.linalg.norm(T[1:-1, 1:-1] - Tr[1:-1, 1:-1]) / np.linalg.norm(Tr[1:-1, 1:-1])) <= 1e-10
     assert np.array_equal(mesh.vel_u_array(), ref.field(1), equal_nan=True)
     assert np.array_equal(mesh.vel_v_array(), ref.field(2), equal_nan=True)
 
@@ -302,3 +302,13 @@ def test_failed_step_returns_nan_and_python_errors_surface(krylov):
     state["armed"] = False
     d = sim2.timestep(0.25)
     assert math.isfinite(d) and not sim2.failed()
+    # The step whose sampling failed had already been queued: it ran, the time advanced, and the next call
+    # sampled the boundary values of the new time again before queueing anything.  The object is where a
+    # twin without the failure is after three steps.
+    twin = krylov.ImplicitEulerGMRESSolver10(p["corner1"], p["corner2"], 8, 6, lambda x, y: (0.0, y * (1.0 - y), 0.0),
+                                             krylov.SecondOrderCentered(*p["params"]),
+                                             (krylov.BCType.dirichlet, lambda x, y, t: 0.0), *([zero] * 11))
+    dt = [twin.timestep(0.25) for _ in range(3)]
+    assert d == dt[2]
+    assert sim2.cur_time() == twin.cur_time() == 0.75
+    assert np.array_equal(sim2.mesh().Temp_array(), twin.mesh().Temp_array(), equal_nan=True)
