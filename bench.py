@@ -53,6 +53,9 @@ def parse_args():
                     help="solve every step with the restarted, residual-monitored GMRES(m) to this relative "
                          "residual (not the reference's fixed cycle); the value is then iterations actually done per second")
     ap.add_argument("--max-cycles", type=int, default=20)
+    ap.add_argument("--operator", choices=["stencil", "csr"], default="stencil",
+                    help="csr: the assembled 5-point matrix of the same mesh as a general CSR operator (the stand-alone "
+                         "GMRESSolver.solve(Matrix, Vector) path); a step is then one fixed-m GMRES cycle")
     ap.add_argument("--stored-bands", action="store_true",
                     help="one-sweep steps read the five stored bands instead of evaluating their interior entries")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -131,7 +134,8 @@ def supervise_ranks(args):
         {"KRY_DIST_GRAPH": "0"},                                                  # eager launches only
         {"KRY_DIST_GRAPH": "0", "KRY_DIST_COMM": "torch", "KRY_HALO_OVERLAP": "0"},  # torch.distributed callbacks
     ]
-    job = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"))
+    # the launcher's process id is the same for all ranks of a node and differs between jobs
+    job = "%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"), os.getppid())
     rank = int(os.environ.get("RANK", "0"))
     rc = 1
     for attempt, extra in enumerate(levels):
@@ -161,6 +165,107 @@ def claim_stdout():
     return real
 
 
+def csr_from_bands(bands):
+    """The 5-band operator of a step object (padded layout, bands W S C N E at offsets -P, -1, 0, +1, +P) as CSR with
+    ascending column indices: the diagonal of every row and every non-zero off-diagonal entry."""
+    import numpy as np
+    nb, R, P = bands.shape
+    N = R * P
+    flat = bands.reshape(5, N)
+    offs = (-P, -1, 0, 1, P)
+    k = np.arange(N, dtype=np.int64)
+    jcol = k % P
+    present = []
+    for b, off in enumerate(offs):
+        ok = (k + off >= 0) & (k + off < N) & ((flat[b] != 0.0) | (off == 0))
+        if off == -1:
+            ok &= jcol > 0
+        if off == 1:
+            ok &= jcol < P - 1
+        present.append(ok)
+    counts = np.zeros(N, dtype=np.int64)
+    for ok in present:
+        counts += ok
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    col = np.empty(nnz, dtype=np.int32)
+    val = np.empty(nnz, dtype=np.float64)
+    pos = rowptr[:-1].copy()
+    for b, off in enumerate(offs):  # ascending offsets = ascending columns within a row
+        ok = present[b]
+        col[pos[ok]] = (k[ok] + off).astype(np.int32)
+        val[pos[ok]] = flat[b][ok]
+        pos += ok
+    return rowptr, col, val
+
+
+def run_csr(args, ctx, out_stream):
+    """--operator csr: the general-operator path.  The operator is the assembled implicit-Euler matrix of the mesh
+    (about five entries per row) handed over as CSR; a step is one fixed-m GMRES cycle of a stand-alone solver
+    (Gram-Schmidt chain; the one-sweep kernels serve grid operators only).  The roofline entry is the CSR
+    operator apply alone, timed over separate launches."""
+    import ctypes as C
+    import torch
+    from krylov_amd import capi, host, problems
+    n_side, m, dt = args.mesh, args.m, args.dt
+    t_setup = time.perf_counter()
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(n_side), m=0, bc_time_dependent=False)
+    dev.assemble_system(dt)
+    rowptr, col, val = csr_from_bands(dev.bands())
+    op = host.Operator.csr(ctx, rowptr, col, val)
+    nnz, n = int(rowptr[-1]), int(rowptr.shape[0] - 1)
+    del rowptr, col, val
+    g = host.GMRESSolver(ctx, n, m)
+    b_ptr = dev.rhs_device()
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    for _ in range(args.warmup):
+        g.solve_device(op, b_ptr)
+    ctx.set_kernel_timing(False)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.solve_device(op, b_ptr)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # the operator apply alone: y = A x on device vectors, every launch between two HIP events on the library's stream
+    x_ptr = C.c_void_p(capi.lib().kry_gmres_result_device(g.h))
+    y = torch.empty(n, dtype=torch.float64, device="cuda:%d" % torch.cuda.current_device())
+    applies = 20
+    ctx.set_kernel_timing(True)
+    ctx.kernel_times()
+    for _ in range(applies):
+        capi.check(capi.lib().kry_op_apply_device(op.h, x_ptr, C.c_void_p(y.data_ptr())))
+    ms, cnt = ctx.kernel_times()
+    ctx.set_kernel_timing(False)
+    k = capi.K_NAMES.index("spmv_dots")
+    avg_ms = ms[k] / max(cnt[k], 1)
+    alg = 12.0 * nnz + 8.0 * (n + 1) + 16.0 * n  # values + column indices, row pointers, x read once, y written
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "gmres_arnoldi_iters_per_sec", "value": m * args.steps / elapsed, "unit": "iters/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "general CSR operator: the assembled implicit-Euler matrix of the S-iso %dx%d mesh (%d rows, "
+                               "%d entries), one fixed-m GMRES(%d) cycle per step, stand-alone solver (Gram-Schmidt chain, "
+                               "%d links per sweep)" % (n_side, n_side, n, nnz, m, g.get_mgs_block()),
+                   "mesh": [n_side, n_side], "unknowns": n, "nnz": nnz, "m": m, "operator": "csr", "parallelism": "1 GPU",
+                   "graph": False},
+        "setup_s": round(t_setup, 2),
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_csr<0> (CSR operator apply: entries fetched side by side and parked in "
+                                                "LDS as products, one lane adds up one row in the stored order)",
+                     "kernel_class": "spmv_dots", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "alg_bytes_per_launch": alg,
+                     "bytes_per_row": round(alg / n, 2), "avg_launch_ms": round(avg_ms, 4), "launches_timed": cnt[k],
+                     "measured_in": "%d separate operator applies after the timed region, two HIP events on the library's "
+                                    "stream around every launch" % applies},
+    }
+    print(json.dumps(out), file=out_stream, flush=True)
+
+
 def dist_bench_label():
     from krylov_amd import dist_bench
     return dist_bench.sweep_kernel_label()
@@ -182,10 +287,13 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29541"),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
-    if world > 1 and not args.dist_child:
+    # KRY_BENCH_FORCE_DIST=1: take the multi-rank path with a single rank as well (rehearsal of the RCCL transport
+    # and of graph-replayed steps with collectives in a group of one)
+    multi = world > 1 or os.environ.get("KRY_BENCH_FORCE_DIST") == "1"
+    if multi and not args.dist_child:
         sys.exit(supervise_ranks(args))
     out_stream = claim_stdout()
-    if world > 1:
+    if multi:
         from krylov_amd import dist_bench
         return dist_bench.run(args, world, rank, local_rank, out_stream)
 
@@ -193,6 +301,8 @@ def main():
     from krylov_amd import capi, host, problems
 
     ctx = host.Context(local_rank)
+    if args.operator == "csr":
+        return run_csr(args, ctx, out_stream)
     n_side, m, dt = args.mesh, args.m, args.dt
     # the restarted solver reads its state on the host between cycles: its steps are not captured
     graph = args.graph and not args.extended > 0.0

@@ -801,7 +801,10 @@ int kry_op_apply_device(kry_op *op, const double *x_dev, double *y_dev) {
   if (!op || !x_dev || !y_dev) return fail(KRY_ERR_INVALID, "NULL argument");
   if (x_dev == y_dev) return fail(KRY_ERR_INVALID, "x and y must not alias");
   HIPCHK(hipSetDevice(op->ctx->device));
-  op_apply_async(op, x_dev, y_dev, 0, nullptr, 0, nullptr, nullptr, false);
+  {
+    ScopedKernelTimer t(op->ctx, KRY_K_SPMV);
+    op_apply_async(op, x_dev, y_dev, 0, nullptr, 0, nullptr, nullptr, false);
+  }
   return launch_ok("kry_op_apply_device");
 }
 
@@ -1382,10 +1385,17 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
   KCHK(fused_totals(g, 2 * (i0 + 1) - 1, np));
   // the last step's norm from the last sweep's sums; the closing kernel then only runs where that cancels
   const int *skip = norm_from_sums(g, op) ? g->fskip : nullptr;
+  // On one rank, outside the monitored mode, a sweep evaluates its own coefficients in its prologue (no separate
+  // launch between two sweeps); the hand-over step and the last step keep the launch of their own.
+  static const bool fold_env = !(getenv("KRY_FOLD_COEFFS") && atoi(getenv("KRY_FOLD_COEFFS")) == 0);
+  const bool fold = fold_env && !ranks && !ext;
+  const CoefIn cin{g->ftot, g->G, m + 1, g->H, m, g->fsigma};
   for (int i = i0; i < m; i++) {
     const bool boot = i == i0;
-    launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef, g->fsigma,
-                        (skip && i == m - 1) ? g->fskip : nullptr);
+    const bool folded = fold && !boot && i < m - 1;
+    if (!folded)
+      launch_fused_coeffs(st, g->ftot, i, boot, g->G, m + 1, g->H, m, g->fcoef, g->fsigma,
+                          (skip && i == m - 1) ? g->fskip : nullptr);
     if (ext && !boot) {
       ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
       launch_givens(st, g->H, m, i - 1, R, rot_c, rot_s, gv, g->ext);
@@ -1420,7 +1430,7 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
         if (ranks) KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
         launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks, gen,
-                             kSweepAll, g->strips);
+                             kSweepAll, g->strips, folded ? &cin : nullptr);
       }
       KCHK(fused_totals(g, 2 * i + 4 + (fused_sweep_has_tt(i) ? 1 : 0), np));
     } else {

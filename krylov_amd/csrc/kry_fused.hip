@@ -159,12 +159,17 @@ __device__ __forceinline__ double gdiag_of(const BandGen &gen) { return *gen.cdi
 // wavefront does the recurrence.  gs: i (i + 1) doubles of LDS.
 constexpr double kNormFromSumsMin = 1.0 / 64.0;  // share of ||A v||^2 the norm from sums has to keep
 
+// write_global: store the results (G, H, coef, sigma, the norm flag); cf != nullptr (LDS, 65 doubles): also leave
+// coef[k] in cf[k] and sigma_i in cf[64] for the calling workgroup.  A sweep that evaluates its own coefficients
+// calls this in every workgroup (same totals, same expression tree, hence the same bits everywhere) and lets its
+// first workgroup store.  Contains a barrier: to be called by all threads of the workgroup.
 __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int boot, double *G, int gld, double *H,
-                                                  int m, double *coef, double *sigma, double *gs, int *norm_flag) {
+                                                  int m, double *coef, double *sigma, double *gs, int *norm_flag,
+                                                  bool write_global = true, double *cf = nullptr) {
   const int lane = threadIdx.x;  // only lanes of the first wavefront own a vector
   const int gp = i + 1;          // row pitch of gs
   const double nrm = boot ? 1.0 : sqrt(tot[2 * i + 1]);
-  const double sk = (boot || lane >= i) ? (lane == i ? nrm : 1.0) : sigma[lane];  // sigma of "my" vector
+  const double sk = (boot || lane >= i) ? (lane == i ? nrm : 1.0) : sigma[lane < kFusedCoef ? lane : 0];  // sigma of "my" vector
   // earlier Gram columns
   for (int e = threadIdx.x; e < i * i; e += blockDim.x) {
     const int a = e / i, k = e % i;
@@ -173,7 +178,7 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
   if (lane < i) {
     const double g = boot ? tot[i + 1 + lane] : tot[i + 1 + lane] / sk / nrm;
     gs[lane * gp + i] = g;
-    G[(size_t)lane * gld + i] = g;
+    if (write_global) G[(size_t)lane * gld + i] = g;
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
@@ -189,13 +194,20 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
     if (lane > a && lane <= i) v = v - ha * gs[a * gp + lane];
   }
   if (lane <= i) {
-    coef[lane] = v / sk;
-    H[(size_t)lane * m + i] = v;
-    if (boot || lane == i) sigma[lane] = sk;
+    const double c = v / sk;
+    if (cf != nullptr) cf[lane] = c;
+    if (write_global) {
+      coef[lane] = c;
+      H[(size_t)lane * m + i] = v;
+      if (boot || lane == i) sigma[lane] = sk;
+    }
   }
   if (lane == 0) {
-    coef[kFusedNormSlot] = nrm;
-    if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
+    if (cf != nullptr) cf[64] = nrm;
+    if (write_global) {
+      coef[kFusedNormSlot] = nrm;
+      if (!boot && i > 0) H[(size_t)i * m + (i - 1)] = nrm;
+    }
   }
   if (norm_flag != nullptr) {
     // ||A v_i - sum_k h_k v_k||^2 = ||A v_i||^2 - sum_k h_k^2;  <t, t> is the last total of the previous sweep
@@ -204,7 +216,7 @@ __device__ __forceinline__ void fused_coeffs_body(const double *tot, int i, int 
     const double ww = boot ? 0.0 : tot[2 * i + 2] / nrm / nrm;
     const double r2 = ww - hs;
     const bool ok = !boot && r2 >= kNormFromSumsMin * ww && ww > 0.0 && ww <= 1.7e308;  // false for anything not finite
-    if (lane == 0) {
+    if (lane == 0 && write_global) {
       *norm_flag = ok ? 1 : 0;
       if (ok) {
         const double nn = sqrt(r2);
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
                                                           double *__restrict__ u_out,
                                                           double *__restrict__ part,
                                                           const double *__restrict__ u_halo, int s_halo,
-                                                          const int *__restrict__ stop) {
+                                                          const int *__restrict__ stop, CoefIn cfin) {
   if (stopped(stop)) return;
   constexpr bool TT = sweep_has_tt(NV);
   constexpr int NQ = 2 * NV + 4 + (TT ? 1 : 0);
@@ -300,8 +312,20 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   };
 
   static_assert(NV + 1 <= 64, "one coefficient per lane");
-  const double hpack = coef[(t & 63) <= NV ? (t & 63) : 0];
-  const double nrm = coef[kFusedNormSlot];
+  double hpack, nrm;
+  if (cfin.tot != nullptr) {
+    // this step's coefficients from the previous sweep's totals; the scratch lives where the rows of the basis
+    // vectors will wait (not in use before the loop)
+    double *gs = keep, *cf = keep + NV * (NV + 1);
+    fused_coeffs_body(cfin.tot, NV, 0, cfin.G, cfin.gld, cfin.H, cfin.m, const_cast<double *>(coef), cfin.sigma, gs, nullptr,
+                      blockIdx.x == 0, cf);
+    __syncthreads();
+    hpack = cf[(t & 63) <= NV ? (t & 63) : 0];
+    nrm = cf[64];
+  } else {
+    hpack = coef[(t & 63) <= NV ? (t & 63) : 0];
+    nrm = coef[kFusedNormSlot];
+  }
 
   double acc[NQ];
 #pragma unroll
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
                                                                 double *__restrict__ u_out,
                                                                 double *__restrict__ part,
                                                                 const double *__restrict__ u_halo, int s_halo,
-                                                                const int *__restrict__ stop) {
+                                                                const int *__restrict__ stop, CoefIn cfin) {
   if (stopped(stop)) return;
   constexpr bool TT = sweep_has_tt(NV);
   constexpr int NQ = 2 * NV + 4 + (TT ? 1 : 0);
@@ -602,8 +626,20 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   };
   const int kb = half ? NA : 0;  // first vector of this half
   // lane k: the coefficient of this half's k-th vector (half 1: and that of s_NV in lane NB)
-  const double hpack = coef[kb + lane <= NV ? kb + lane : 0];
-  const double nrm = coef[kFusedNormSlot];
+  double hpack, nrm;
+  if (cfin.tot != nullptr) {
+    // this step's coefficients from the previous sweep's totals (scratch: the start of the LDS, not in use yet)
+    double *gs = lds, *cf = lds + NV * (NV + 1);
+    fused_coeffs_body(cfin.tot, NV, 0, cfin.G, cfin.gld, cfin.H, cfin.m, const_cast<double *>(coef), cfin.sigma, gs, nullptr,
+                      blockIdx.x == 0, cf);
+    __syncthreads();
+    hpack = cf[kb + lane <= NV ? kb + lane : 0];
+    nrm = cf[64];
+    __syncthreads();  // sring, which the lines below fill, may lie inside that scratch
+  } else {
+    hpack = coef[kb + lane <= NV ? kb + lane : 0];
+    nrm = coef[kFusedNormSlot];
+  }
   const double *Vh = V + (int64_t)kb * ld;
 
   if (half == 0) {
@@ -1173,7 +1209,8 @@ int fused_sets(int nv) {
   static std::atomic<int> table[kDeepSetsUpto + 1];
   static std::atomic<int> ready{0};
   if (!ready.load(std::memory_order_acquire)) {
-    for (int i = 0; i <= kDeepSetsUpto; i++) table[i].store(2, std::memory_order_relaxed);
+    // measured per step on an 8192 x 8192 grid: three sets pay with 8 to 10 earlier vectors (4 to 6 %), nowhere else
+    for (int i = 0; i <= kDeepSetsUpto; i++) table[i].store(i >= 8 && i <= 10 ? 3 : 2, std::memory_order_relaxed);
     if (const char *e = getenv("KRY_FUSED_SETS")) {
       int i = 0;
       for (const char *p = e; *p && i <= kDeepSetsUpto; i++) {
@@ -1241,12 +1278,12 @@ constexpr size_t fused_lds() {
 template <int NV, bool GEN, int S>
 void launch_fused_sets(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
                        int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
-                       const double *u_halo, int s_halo, int launch_bands) {
+                       const double *u_halo, int s_halo, int launch_bands, const CoefIn &cin) {
   constexpr size_t lds = fused_lds<NV>();
   static std::atomic<uint64_t> configured{0};
   allow_lds(&k_arnoldi_fused<NV, GEN, S>, lds, configured, "LDS size of the one-sweep kernel");
   hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN, S>), dim3(geo.nstrips * launch_bands), dim3(kBlock), lds, st, geo, b, gen, V,
-                     ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
+                     ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current(), cin);
 }
 
 template <int NV, int S>
@@ -1262,15 +1299,15 @@ int resident_t() {
 template <int NV, bool GEN>
 void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen &gen, const double *V,
                     int64_t ld, const double *u_in, const double *coef, double *u_out, double *part,
-                    const double *u_halo, int s_halo, int launch_bands) {
+                    const double *u_halo, int s_halo, int launch_bands, const CoefIn &cin) {
   constexpr size_t lds = fused_lds<NV>();
   static_assert(lds <= 160 * 1024, "LDS of one compute unit");
   if constexpr (GEN && NV <= kDeepSetsUpto) {
     const int sets = fused_sets(NV);
     if (sets == 3)
-      return launch_fused_sets<NV, GEN, 3>(st, geo, b, gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_bands);
+      return launch_fused_sets<NV, GEN, 3>(st, geo, b, gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_bands, cin);
     if (sets == 4)
-      return launch_fused_sets<NV, GEN, 4>(st, geo, b, gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_bands);
+      return launch_fused_sets<NV, GEN, 4>(st, geo, b, gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_bands, cin);
   }
   static std::atomic<uint64_t> configured{0};
   allow_lds(&k_arnoldi_fused<NV, GEN>, lds, configured, "LDS size of the one-sweep kernel");
@@ -1283,12 +1320,12 @@ void launch_fused_t(hipStream_t st, const FusedGeom &geo, const Bands &b, const 
       static std::atomic<uint64_t> configured2{0};
       allow_lds(&k_arnoldi_split<NV, GEN>, lds2, configured2, "LDS size of the 512-thread one-sweep kernel");
       hipLaunchKernelGGL((k_arnoldi_split<NV, GEN>), dim3(geo.nstrips * launch_bands), dim3(kSplitBlock), lds2, st, geo, b,
-                         gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
+                         gen, V, ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current(), cin);
       return;
     }
   }
   hipLaunchKernelGGL((k_arnoldi_fused<NV, GEN>), dim3(geo.nstrips * launch_bands), dim3(kBlock), lds, st, geo, b, gen, V,
-                     ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current());
+                     ld, u_in, coef, u_out, part, u_halo, s_halo, launch_predicate_current(), cin);
 }
 
 struct CloseArgs {
@@ -1316,16 +1353,18 @@ void launch_close_t(hipStream_t st, const CloseArgs &a) {
 template <int NV = kFusedMaxM - 1>
 struct FusedTable {
   static void sweep(int nv, hipStream_t st, const FusedGeom &geo, const Bands &b, const BandGen *gen, const double *V,
-                    int64_t ld, const double *coef, double *part, bool u_halo, int s_halo, int launch_bands) {
+                    int64_t ld, const double *coef, double *part, bool u_halo, int s_halo, int launch_bands,
+                    const CoefIn &cin) {
     if (nv == NV) {
       double *u_out = const_cast<double *>(V) + (int64_t)(NV + 1) * ld;
       const double *uh = u_halo ? u_out : nullptr;
       if (gen)
-        launch_fused_t<NV, true>(st, geo, b, *gen, V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo, launch_bands);
+        launch_fused_t<NV, true>(st, geo, b, *gen, V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo, launch_bands, cin);
       else
-        launch_fused_t<NV, false>(st, geo, b, BandGen(), V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo, launch_bands);
+        launch_fused_t<NV, false>(st, geo, b, BandGen(), V, ld, V + (int64_t)NV * ld, coef, u_out, part, uh, s_halo, launch_bands,
+                                  cin);
     } else {
-      FusedTable<NV - 1>::sweep(nv, st, geo, b, gen, V, ld, coef, part, u_halo, s_halo, launch_bands);
+      FusedTable<NV - 1>::sweep(nv, st, geo, b, gen, V, ld, coef, part, u_halo, s_halo, launch_bands, cin);
     }
   }
   static void close(int nv, hipStream_t st, const CloseArgs &a) {
@@ -1345,7 +1384,7 @@ struct FusedTable {
 template <>
 struct FusedTable<-1> {
   static void sweep(int, hipStream_t, const FusedGeom &, const Bands &, const BandGen *, const double *, int64_t,
-                    const double *, double *, bool, int, int) {}
+                    const double *, double *, bool, int, int, const CoefIn &) {}
   static void close(int, hipStream_t, const CloseArgs &) {}
   static int resident(int, int) { return 0; }
 };
@@ -1430,7 +1469,7 @@ void launch_unscale_strips(hipStream_t st, const double *src, const double *sigm
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen, int which,
-                          bool strip_major) {
+                          bool strip_major, const CoefIn *cin) {
   FusedGeom g = fused_geom(rows, cols, nv);
   if (strip_major) {
     g.sm = 1;
@@ -1450,7 +1489,7 @@ void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Band
       launch_bands = 2;
     }
   }
-  FusedTable<>::sweep(nv, st, g, b, gen, V, ld, coef, part, has_halo, has_halo ? 1 : 0, launch_bands);
+  FusedTable<>::sweep(nv, st, g, b, gen, V, ld, coef, part, has_halo, has_halo ? 1 : 0, launch_bands, cin ? *cin : CoefIn());
 }
 
 bool fused_bands_splittable(int nv, int rows, int cols) { return fused_geom(rows, cols, nv).nbands >= 3; }

@@ -195,10 +195,23 @@ int get_split_upto();  // last step served by it
 // are fewer than three bands).  The partial sums of an interior and an edge launch together
 // fill the array of an all-bands launch.
 enum { kSweepAll = 0, kSweepInterior = 1, kSweepEdges = 2 };
+// A sweep may evaluate its own coefficients (what launch_fused_coeffs does as a launch of its own) in its prologue,
+// from the totals of the previous sweep: every workgroup evaluates the same recurrence on the same totals (same
+// bits everywhere), the first one stores G, H, coef and sigma.  One dependent launch per Arnoldi step less.
+// tot == nullptr: the coefficients are read from `coef` as a separate launch left them.
+struct CoefIn {
+  const double *tot = nullptr;
+  double *G = nullptr;
+  int gld = 0;
+  double *H = nullptr;
+  int m = 0;
+  double *sigma = nullptr;
+};
 // strip_major (with gen only): the basis vectors and gen's velocity snapshots are strip-major (StripMap).
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo,
-                          const BandGen *gen = nullptr, int which = kSweepAll, bool strip_major = false);
+                          const BandGen *gen = nullptr, int which = kSweepAll, bool strip_major = false,
+                          const CoefIn *cin = nullptr);
 // The strip-major layout of vectors on a rows x cols grid, and its size in doubles.
 StripMap strip_map(int rows, int cols);
 inline int64_t strip_major_size(int rows, int cols) {

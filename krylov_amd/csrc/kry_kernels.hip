@@ -560,7 +560,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
   if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }
 
-// CSR, one row per lane, stored entries in ascending column order.
+// CSR, stored entries in ascending column order.  The row sum of include/matrix.hpp:23-33 is sequential
+// (result = 0, then += in ascending column order), so one lane adds up one row -- but a lane that also fetched
+// its own row would read val / col at a stride of one row length, a different cache line per lane.  Here a
+// workgroup owns kBlock consecutive rows, whose entries form ONE contiguous piece of val / col: all lanes fetch
+// that piece side by side (coalesced, streamed once), multiply every entry by its x (a product needs no order)
+// and park the products in LDS; then lane r adds up the products of row r one after the other, in the stored
+// order: the same operations on the same operands as `sum += val[p] * x[col[p]]`, hence the same bits.
+constexpr int kCsrChunk = 2048;  // products parked per round (16 KB of LDS)
+
 template <int KC>
 __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col,
@@ -572,14 +580,29 @@ __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__
   if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
+  __shared__ double prod[kCsrChunk];
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
-  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+  for (int64_t r0 = (int64_t)blockIdx.x * kBlock; r0 < n; r0 += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = r0 + threadIdx.x;
+    const int64_t rend = r0 + kBlock < n ? r0 + kBlock : n;
+    const int64_t p0 = rowptr[r0], p1 = rowptr[rend];            // the workgroup's piece of val / col
+    const int64_t mb = r < n ? rowptr[r] : p1, me = r < n ? rowptr[r + 1] : p1;  // this lane's row
     double sum = 0.0;
-    for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) sum = sum + val[p] * x[col[p]];
-    y[r] = sum;
-    if (KC > 0) accum_scalar<KC>(sum, cbase, ld, r, acc);
+    for (int64_t c0 = p0; c0 < p1; c0 += kCsrChunk) {
+      const int64_t c1 = c0 + kCsrChunk < p1 ? c0 + kCsrChunk : p1;
+      for (int64_t p = c0 + threadIdx.x; p < c1; p += kBlock)
+        prod[p - c0] = __builtin_nontemporal_load(&val[p]) * x[__builtin_nontemporal_load(&col[p])];
+      __syncthreads();
+      const int64_t a = mb > c0 ? mb : c0, b = me < c1 ? me : c1;
+      for (int64_t p = a; p < b; p++) sum = sum + prod[p - c0];
+      __syncthreads();
+    }
+    if (r < n) {
+      y[r] = sum;
+      if (KC > 0) accum_scalar<KC>(sum, cbase, ld, r, acc);
+    }
   }
   if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }

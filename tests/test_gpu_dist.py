@@ -22,7 +22,7 @@ def rel(a, b):
     (3, "s_iso", 20, 300, 20, 0),  # rows wider than one strip of the one-sweep kernels
     (3, "s_iso", 1, 40, 5, 0),     # one grid row per rank
     (2, "s_iso", 400, 40, 12, 0),  # six bands of rows per rank: interior bands swept while the halo rows travel
-    (3, "s_iso", 330, 270, 20, 0),  # three bands, two strips, the 512-thread kernel from step 14 on
+    (3, "s_iso", 330, 270, 24, 0),  # three bands, two strips, the 512-thread kernel from step 18 on
 ])
 def test_slabs_match_single_rank(tmp_path, ctx, oracle, nranks, name, cx, cy, m, tdp):
     steps = 3
@@ -110,12 +110,54 @@ def test_bench_contract_two_ranks_shared_gpu(tmp_path):
         assert key in d
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64"
     assert d["collectives"] == "torch" and d["collectives_selfcheck_rel_err"] <= 1e-9
+    # host-staged collectives cannot be captured: the step form is eager, nothing was turned down, first attempt
+    assert d["graph"] is False and d["config"]["graph"] is False
+    assert d["rejected_candidates"] == [] and d["attempt"] == 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
     # the row blocks run the one-sweep Arnoldi kernels (8 of the 10 steps per cycle; the last is the closing sweep)
     assert d["kernels"]["arnoldi_fused"]["launches"] == 2 * 7
     assert abs(d["value"] - 10 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
 
 
-@pytest.mark.parametrize("nranks,cx,cy,m", [(2, 400, 40, 12), (3, 330, 270, 20)])
+def _run_bench(extra_env, nproc, port, args=()):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "2",
+           "--warmup", "1", "--mesh", "256", "--gmres-m", "10", *args]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0]), p.stderr
+
+
+def test_bench_graph_replayed_steps_with_library_side_rccl_one_rank():
+    """The multi-rank path of bench.py in a group of ONE rank (all this build can run on real RCCL): the start-up
+    check puts the graph-replayed step with the library's own RCCL calls first, validates it against the
+    single-rank replica, and the timed region replays the captured step."""
+    d, _ = _run_bench({"KRY_BENCH_FORCE_DIST": "1"}, 1, 29617, ["--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["collectives"] == "rccl"
+    assert d["graph"] is True and d["config"]["graph"] is True
+    assert d["rejected_candidates"] == [] and d["attempt"] == 0
+    assert d["collectives_selfcheck_rel_err"] <= 1e-9
+
+
+def test_bench_watchdog_and_fresh_processes_after_a_stalled_start(tmp_path):
+    """A rank that makes no progress in the start-up check (simulated in the first attempt) is ended by its watchdog
+    with exit code 3; every rank's supervisor then starts a fresh process with the next, more conservative
+    configuration, and the job still delivers its line (attempt 1)."""
+    d, err = _run_bench({"KRY_DIST_BACKEND": "gloo", "KRY_DIST_TEST_HANG_ATTEMPTS": "0", "KRY_DIST_STARTUP_LIMIT": "6",
+                         "TMPDIR": str(tmp_path)}, 2, 29619, ["--no-cpu-baseline"])
+    assert d["attempt"] == 1 and d["n_gpus"] == 2
+    assert "made no progress" in err and "exit code 3" in err
+
+
+@pytest.mark.parametrize("nranks,cx,cy,m", [(2, 400, 40, 12), (3, 330, 270, 24)])
 def test_halo_overlap_changes_no_bit(tmp_path, monkeypatch, nranks, cx, cy, m):
     """On row blocks the one-sweep steps sweep the interior bands of rows while the
     neighbours' rows of the new vector travel on a second stream, then the first
