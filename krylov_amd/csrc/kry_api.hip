@@ -789,7 +789,16 @@ static void op_apply_async(kry_op *op, const double *x, double *y, int kc, const
   hipStream_t st = op->ctx->stream;
   if (op->kind == 0) {
     Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
-    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts, x_has_halo);
+    // operators assembled by a step object: the band entries evaluated from two velocity snapshots instead of
+    // five streamed bands (same bits; experimentation knob KRY_SPMV_GEN=0 reads the bands)
+    // Only where the apply streams enough partner vectors for the evaluation (eight divisions per lane and
+    // round) to hide behind the memory traffic: with a single partner the kernel takes 0.79 instead of 0.61 ms
+    // on an 8192 x 8192 grid; from four partners on it pays (GMRES(50) with the line preconditioner on that
+    // grid: 355.5 ms per step with stored bands, 348.0 from four partners on, 348.5 from eight, 350.0 from sixteen).
+    // KRY_SPMV_GEN=k: from k partners on (0: never).
+    static const int gen_min_kc = getenv("KRY_SPMV_GEN") ? atoi(getenv("KRY_SPMV_GEN")) : 4;
+    const BandGen *gen = (gen_min_kc > 0 && kc >= gen_min_kc && op->has_gen && op->use_gen) ? &op->gen : nullptr;
+    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts, x_has_halo, gen);
   } else {
     launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, kc, cbase, ld, part, nparts);
   }
@@ -1652,13 +1661,19 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
   const int m = g->m;
   const int K = g->kblock;
   // bytes of the operator itself: five bands, or CSR values + indices + row pointers
+  // (grid operators with a recipe: the chain's operator kernel evaluates the entries from two velocity arrays
+  // when the rows have even length)
+  const int gen_min_kc = getenv("KRY_SPMV_GEN") ? atoi(getenv("KRY_SPMV_GEN")) : 4;
+  const bool spmv_gen = op->kind == 0 && op->has_gen && op->use_gen && op->cols % 2 == 0 && op->n % 2 == 0 && gen_min_kc > 0;
   const double opb = op->kind == 0 ? 5.0 * N : 12.0 * (double)op->nnz + 8.0 * (double)(op->n + 1);
+  // bytes of the operator as the chain's apply with kp partner vectors reads it
+  auto op_bytes = [&](int kp) { return (spmv_gen && kp >= gen_min_kc) ? 2.0 * N : opb; };
   const bool fused = fused_usable(g, op);
   const int chain_steps = fused ? fused_first(g) : m;
   for (int j = 0; j < chain_steps; j++) {
     const int nv = j + 1;
     int kp = nv < K ? nv : K;
-    bytes[KRY_K_SPMV] += opb + N + N + kp * N;  // operator, x read, y written, first group read
+    bytes[KRY_K_SPMV] += op_bytes(kp) + N + N + kp * N;  // operator, x read, y written, first group read
     launches[KRY_K_SPMV] += 1;
     for (int cs = kp; cs < nv; cs += K) {
       const int kc = nv - cs < K ? nv - cs : K;
@@ -1672,7 +1687,7 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
   }
   if (fused) {
     const int i0 = fused_first(g);
-    bytes[KRY_K_SPMV] += opb + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
+    bytes[KRY_K_SPMV] += op_bytes(i0 + 1) + N + N + (i0 + 1) * N;  // t = A v_i0 with its dots
     launches[KRY_K_SPMV] += 1;
     // the operator as a sweep reads it: five bands, or the two velocity arrays its interior
     // entries are evaluated from (no stored band is read then)
@@ -1997,8 +2012,8 @@ int kry_ie_init_offdiag(kry_ie *ie) {
   launch_offdiag(ie->ctx->stream, ie->g, ie->fld[1], ie->fld[2], ie->band[0], ie->band[1], ie->band[2],
                  ie->band[3], ie->band[4]);
   KCHK(launch_ok("init_offdiag"));
-  if (ie->solver && ie->solver->fparts) {
-    // the recipe the one-sweep kernels evaluate the interior band entries from
+  if (ie->solver) {
+    // the recipe the one-sweep kernels (and the chain's operator kernel) evaluate the interior band entries from
     const int P = ie->g.cy + 2;
     const int64_t fld_len = ie->halo + (ie->nloc + 31) / 32 * 32 + ie->halo;
     for (int f = 0; f < 2; f++) {

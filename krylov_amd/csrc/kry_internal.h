@@ -114,9 +114,11 @@ void launch_scale_from(hipStream_t st, const double *src, double *dst, const dou
 
 // y = A x; with kc > 0 also the partial sums of <y, c_k> and <c_a, c_{kc-1}> for the
 // kc vectors cbase + k*ld (layout: part[q * nparts + workgroup], dots first)
+// gen != nullptr (rows of even length only; otherwise ignored): the band entries are evaluated from the recipe
+// instead of being read (grid-order velocity snapshots with a grid row in front and behind)
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                          double *y, int kc, const double *cbase, int64_t ld, double *part,
-                         int *nparts, bool x_has_halo);
+                         int *nparts, bool x_has_halo, const BandGen *gen = nullptr);
 // tot[q] = sum_i part[q * np + i], q < nq (one workgroup)
 void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot);
 void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,

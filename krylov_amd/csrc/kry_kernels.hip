@@ -492,17 +492,49 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
 // unknowns; band, centre and +-P accesses are aligned 16-byte loads.  Bands,
 // partners and the result are streamed non-temporally; x keeps the default
 // policy because its rows are reused by the neighbouring rows' sums.
-template <int KC, bool HALO, int U>
+// The value itself, behind an empty asm statement: keeps a select on the result of a division a select
+// (the compiler would otherwise branch around the division).
+__device__ __forceinline__ double opaque_value(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// The five band entries of the unknown in mesh row ip, column c of an assembled implicit-Euler operator,
+// from the velocities next to it: SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1
+// (include/space_disc.hpp:83-113) with the operations of k_offdiag for interior cells, the rows of ghost
+// cells as k_assemble leaves them (include/time_disc.hpp:304-337): the same bits as the stored bands.
+__device__ __forceinline__ void gen_band_entries(const BandGen &gen, double gdiag, int ip, int c, double um, double up,
+                                                 double vm, double vp, double (&out)[5]) {
+  const bool xin = ip >= 1 && ip <= gen.cx, yin = c >= 1 && c <= gen.cy;
+  const double iw = opaque_value((-um / 2.0 - gen.kx) / gen.dx);
+  const double is = opaque_value((-vm / 2.0 - gen.ky) / gen.dy);
+  const double in = opaque_value((vp / 2.0 - gen.ky) / gen.dy);
+  const double ie = opaque_value((up / 2.0 - gen.kx) / gen.dx);
+  const bool inner = xin && yin;
+  out[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
+  out[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);
+  out[3] = inner ? in : ((xin && c == 0) ? 1.0 : 0.0);
+  out[4] = inner ? ie : ((yin && ip == 0) ? 1.0 : 0.0);
+  out[2] = inner ? gdiag : (xin ? (c == 0 ? gen.dg_bottom : gen.dg_top) : (yin ? gen.dg_left : 1.0));
+}
+
+// GEN: the band entries are not read but evaluated from the recipe `gen` (two velocity snapshots instead of
+// five bands: three streamed arrays less per apply).
+template <int KC, bool HALO, int U, bool GEN = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, int P,
                                                              const double *__restrict__ x,
                                                              double *__restrict__ y,
                                                              const double *__restrict__ cbase, int64_t ld,
-                                                             double *__restrict__ part, const int *__restrict__ stop) {
+                                                             double *__restrict__ part, const int *__restrict__ stop,
+                                                             BandGen gen = BandGen()) {
   if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
   const int64_t n2 = n >> 1;
   const int64_t P2 = P >> 1;
+  const double gdiag = GEN ? *gen.cdiag : 0.0;
+  const d2 *gu2 = reinterpret_cast<const d2 *>(gen.u);
+  const d2 *gv2 = reinterpret_cast<const d2 *>(gen.v);
   const d2 *x2 = reinterpret_cast<const d2 *>(x);
   const d2 *bw = reinterpret_cast<const d2 *>(b.w);
   const d2 *bs = reinterpret_cast<const d2 *>(b.s);
@@ -526,7 +558,28 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
         const d2 xe = (HALO || i + P2 < n2) ? x2[i + P2] : zero;
         const double xm1 = (HALO || k >= 1) ? x[k - 1] : 0.0;
         const double xp2 = (HALO || k + 2 < n) ? x[k + 2] : 0.0;
-        const d2 cw = ld_nt(&bw[i]), cs = ld_nt(&bs[i]), cc = ld_nt(&bc[i]), cn = ld_nt(&bn[i]), ce = ld_nt(&be[i]);
+        d2 cw, cs, cc, cn, ce;
+        if (GEN) {
+          // the velocity snapshots carry a grid row in front and behind (like the fields), so no bounds checks
+          const d2 um = ld_nt(&gu2[i - P2]), up = ld_nt(&gu2[i + P2]);
+          const d2 vc = gv2[i];
+          const double vm1 = gen.v[k - 1], vp2 = gen.v[k + 2];
+          const int row = (int)((uint32_t)k / (uint32_t)P), col0 = (int)k - row * P;
+          double e0[5], e1[5];
+          gen_band_entries(gen, gdiag, gen.row0 + row, col0, um.x, up.x, vm1, vc.y, e0);
+          gen_band_entries(gen, gdiag, gen.row0 + row, col0 + 1, um.y, up.y, vc.x, vp2, e1);
+          cw = {e0[0], e1[0]};
+          cs = {e0[1], e1[1]};
+          cc = {e0[2], e1[2]};
+          cn = {e0[3], e1[3]};
+          ce = {e0[4], e1[4]};
+        } else {
+          cw = ld_nt(&bw[i]);
+          cs = ld_nt(&bs[i]);
+          cc = ld_nt(&bc[i]);
+          cn = ld_nt(&bn[i]);
+          ce = ld_nt(&be[i]);
+        }
         d2 cv[KC > 0 ? KC : 1];
 #pragma unroll
         for (int a = 0; a < KC; a++) cv[a] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)a * ld) + i);
@@ -2021,7 +2074,8 @@ void launch_scale_from(hipStream_t st, const double *src, double *dst, const dou
 
 template <int KC, bool HALO>
 static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
-                                  double *y, const double *cbase, int64_t ld, double *part, int *nparts) {
+                                  double *y, const double *cbase, int64_t ld, double *part, int *nparts,
+                                  const BandGen *gen) {
   const bool vec = (cols % 2 == 0) && (n % 2 == 0);
   // 13+ streams with cached x rows: two elements per lane, one workgroup per CU (measured optimum)
   constexpr int U = 2;
@@ -2031,8 +2085,12 @@ static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int
     g = (int)(tiles < 256 ? tiles : 256);
   }
   if (nparts) *nparts = g;
-  if (vec)
-    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop);
+  if (vec && gen != nullptr)
+    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U, true>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part,
+                       t_stop, *gen);
+  else if (vec)
+    hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U, false>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part,
+                       t_stop, BandGen());
   else
     hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop);
 }
@@ -2041,32 +2099,33 @@ static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int
 template <bool HALO, int KC = kMgsBlock>
 struct SpmvStencilKc {
   static void go(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x, double *y, int kc,
-                 const double *cbase, int64_t ld, double *part, int *nparts) {
+                 const double *cbase, int64_t ld, double *part, int *nparts, const BandGen *gen) {
     if (kc == KC)
-      launch_spmv_stencil_t<KC, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts);
+      launch_spmv_stencil_t<KC, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts, gen);
     else
-      SpmvStencilKc<HALO, KC - 1>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+      SpmvStencilKc<HALO, KC - 1>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
   }
 };
 template <bool HALO>
 struct SpmvStencilKc<HALO, -1> {
   static void go(hipStream_t, const Bands &, int64_t, int, const double *, double *, int, const double *, int64_t,
-                 double *, int *) {}
+                 double *, int *, const BandGen *) {}
 };
 
 template <bool HALO>
 static void launch_spmv_stencil_h(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
-                                  double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
-  SpmvStencilKc<HALO>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+                                  double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts,
+                                  const BandGen *gen) {
+  SpmvStencilKc<HALO>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
 }
 
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                          double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts,
-                         bool x_has_halo) {
+                         bool x_has_halo, const BandGen *gen) {
   if (x_has_halo)
-    launch_spmv_stencil_h<true>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+    launch_spmv_stencil_h<true>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
   else
-    launch_spmv_stencil_h<false>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts);
+    launch_spmv_stencil_h<false>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
 }
 
 void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot) {

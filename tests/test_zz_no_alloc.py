@@ -54,6 +54,40 @@ def test_no_alloc_state_update_equals_existing_entry_point(ctx):
     assert math.isnan(got_max)
 
 
+def test_no_alloc_entry_point_under_graph_capture(ctx):
+    """The callers this entry point is for include code under hipGraph capture.  The call is recorded between
+    hipStreamBeginCapture and hipStreamEndCapture on the context's stream (any allocation, free or wait for the
+    device inside it would end the capture with an error) and the graph is replayed twice with new inputs in the
+    same buffers; every replay must give what kry_ie_apply_delta gives."""
+    import torch
+    L = capi.lib()
+    cx, cy = 260, 120
+    rng = np.random.default_rng(11)
+    stream = torch.cuda.ExternalStream(int(ctx.stream), device="cuda:0")
+    T_dev = torch.zeros((cx + 2, cy + 2), dtype=torch.float64, device="cuda:0")
+    d_dev = torch.zeros((cx + 2, cy + 2), dtype=torch.float64, device="cuda:0")
+    out_dev = torch.full((1,), -7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        capi.check(L.kry_apply_delta_noalloc(ctx.h, cx, cy, C.c_void_p(T_dev.data_ptr()), C.c_void_p(d_dev.data_ptr()),
+                                             C.c_void_p(out_dev.data_ptr())))
+    for nan_cells in ([], [(100, 50), (259, 119)]):
+        delta = rng.uniform(-1.0, 1.0, (cx + 2, cy + 2))
+        for (i, j) in nan_cells:
+            delta[i + 1, j + 1] = np.nan
+        T0, want_max, want_T = _existing(ctx, cx, cy, delta)
+        T_dev.copy_(torch.from_numpy(T0))
+        d_dev.copy_(torch.from_numpy(delta))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        got_max = float(out_dev.cpu()[0])
+        assert _same(got_max, want_max), (got_max, want_max)
+        assert np.array_equal(T_dev.cpu().numpy(), want_T, equal_nan=True)
+    assert math.isnan(got_max)
+
+
 def test_no_alloc_rejects_oversized_meshes_and_null_pointers(ctx):
     L = capi.lib()
     fake = C.c_void_p(256)
