@@ -839,6 +839,9 @@ int kry_op_apply(kry_op *op, const double *x_host, double *y_host) {
 // GMRES
 // ---------------------------------------------------------------------------
 static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld + g->halo; }
+// Vector i of a strip-major basis (StripMap): the rows of the m + 1 vectors are interleaved, vector i starts i rows
+// of a strip into the array.
+static double *strip_vec(kry_gmres *g, int i) { return g->V + g->halo + (int64_t)i * kBlock; }
 
 // Latest step at which the one-sweep kernels can take over: the hand-over applies the
 // operator with the dots of all earlier vectors in one kernel (at most kMgsBlock of
@@ -874,9 +877,10 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   g->m = m;
   g->flags = flags;
   const bool one_sweep_possible = !(flags & KRY_GMRES_TDP) && m <= kFusedMaxM && m >= 3;
-  // (the kernels hold positions within a strip-major vector in 32-bit integers)
+  // (the kernels hold positions within a strip's block of the interleaved basis, and within a strip-major snapshot,
+  // in 32-bit integers, and reach one block to either side)
   if (one_sweep_possible && ctx->nranks == 1 && grid_rows > 0 && (int64_t)grid_rows * grid_cols == n &&
-      grid_rows < 8000000 && strip_major_size(grid_rows, grid_cols) < 2147483000LL &&
+      (int64_t)(grid_rows + 2) * (m + 1) * kBlock < 1000000000LL && strip_major_size(grid_rows, grid_cols) < 2147483000LL &&
       !(getenv("KRY_STRIP_MAJOR") && atoi(getenv("KRY_STRIP_MAJOR")) == 0)) {
     // room for the strip-major form of every basis vector
     g->grid_rows = grid_rows;
@@ -1136,7 +1140,7 @@ static int finish_parts(kry_gmres *g, const double **part, int nq, int *np) {
 static void store_v0(kry_gmres *g, const double *src, const double *part, int np, double *out) {
   hipStream_t st = g->ctx->stream;
   if (g->strips) {
-    launch_scale_to_strips(st, src, g->v0, basis(g, 0), part, np, g->grid_rows, g->grid_cols, out);
+    launch_scale_to_strips(st, src, g->v0, strip_vec(g, 0), part, np, g->grid_rows, g->grid_cols, g->m + 1, out);
   } else {
     launch_scale_from(st, src, basis(g, 0), part, np, g->n, out);
   }
@@ -1298,7 +1302,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
     } else {
       ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
       if (g->strips)
-        launch_combine_strips(st, basis(g, 0), g->ld, g->y, m, g->vars, g->grid_rows, g->grid_cols, &g->ext->iters, true,
+        launch_combine_strips(st, strip_vec(g, 0), g->y, m, g->vars, g->grid_rows, g->grid_cols, m + 1, &g->ext->iters, true,
                               g->scaled ? g->fsigma : nullptr);
       else
         launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true,
@@ -1339,9 +1343,9 @@ static bool norm_from_sums(const kry_gmres *g, const kry_op *op) {
 // The closing kernel of a cycle: the update of step m - 1 on the whole vector (slot m) and its squared norm.
 static void launch_close_whole(kry_gmres *g, kry_op *op, int *np, const int *skip) {
   const Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
-  const StripMap smap = g->strips ? strip_map(op->rows, op->cols) : StripMap();
-  launch_arnoldi_close(g->ctx->stream, g->m - 1, b, basis(g, 0), g->ld, g->fcoef, g->n, op->cols, 0, g->n,
-                       g->ctx->nranks > 1, g->fparts, np, g->strips ? &smap : nullptr, skip);
+  const StripMap smap = g->strips ? strip_map(op->rows, op->cols, g->m + 1) : StripMap();
+  launch_arnoldi_close(g->ctx->stream, g->m - 1, b, g->strips ? strip_vec(g, 0) : basis(g, 0), g->strips ? (int64_t)kBlock : g->ld,
+                       g->fcoef, g->n, op->cols, 0, g->n, g->ctx->nranks > 1, g->fparts, np, g->strips ? &smap : nullptr, skip);
 }
 
 // First step of a cycle whose sweep reads the stored bands although it could evaluate them (experimentation
@@ -1438,8 +1442,9 @@ static int fused_steps_async(kry_gmres *g, kry_op *op) {
       } else {
         if (ranks) KCHK(comm_halo(g->ctx, basis(g, i + 1), P, n));
         ScopedKernelTimer t(g->ctx, KRY_K_FUSED);
-        launch_arnoldi_fused(st, i, op->rows, op->cols, b, basis(g, 0), g->ld, g->fcoef, g->fparts, &np, ranks, gen,
-                             kSweepAll, g->strips, folded ? &cin : nullptr);
+        launch_arnoldi_fused(st, i, op->rows, op->cols, b, g->strips ? strip_vec(g, 0) : basis(g, 0),
+                             g->strips ? (int64_t)kBlock : g->ld, g->fcoef, g->fparts, &np, ranks, gen, kSweepAll,
+                             g->strips ? m + 1 : 0, folded ? &cin : nullptr);
       }
       KCHK(fused_totals(g, 2 * i + 4 + (fused_sweep_has_tt(i) ? 1 : 0), np));
     } else {
@@ -1479,7 +1484,7 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   {
     ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
     if (g->strips)
-      launch_combine_strips(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->grid_rows, g->grid_cols, nullptr, false,
+      launch_combine_strips(st, strip_vec(g, 0), g->y, g->m, g->vars, g->grid_rows, g->grid_cols, g->m + 1, nullptr, false,
                             g->scaled ? g->fsigma : nullptr);
     else
       launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n, nullptr, false,
@@ -1595,7 +1600,8 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
   }
   const double *src = basis(g, i);
   if (g->strips) {
-    launch_unscale_strips(g->ctx->stream, src, g->scaled ? g->fsigma : nullptr, i, g->w, g->grid_rows, g->grid_cols);
+    launch_unscale_strips(g->ctx->stream, strip_vec(g, i), g->scaled ? g->fsigma : nullptr, i, g->w, g->grid_rows, g->grid_cols,
+                          g->m + 1);
     KCHK(launch_ok("kry_gmres_subspace_vector"));
     src = g->w;
   } else if (g->scaled) {

@@ -101,13 +101,16 @@ struct FusedGeom {
   // ring is full), so that the writes of all workgroups reach the memory controllers in a few dense batches
   // instead of a steady trickle among the reads.
   int tick = 0;
-  // Strip-major vectors (sm != 0; kernels with generated bands only): the basis vectors and the velocity
-  // snapshots are stored strip by strip.  Strip s is a block of SB = (rows + 2) x kBlock values: one grid row
-  // in front, the rows, one behind; a row holds the kBlock columns the strip's workgroup touches (lane t at
-  // position t: two columns of the strip to the left, the W owned ones, two of the strip to the right), so a
-  // workgroup reads and writes whole aligned 2 KB lines that follow each other in memory as it walks down
-  // its band.  The edge columns are stored twice (by their owner and by its neighbour).
-  int sm = 0, SB = 0;
+  // Strip-major vectors (sm != 0): the basis vectors and the velocity snapshots are stored strip by strip.
+  // Strip s is a block of rows + 2 rows: one grid row in front, the rows, one behind; a row holds the kBlock
+  // columns the strip's workgroup touches (lane t at position t: two columns of the strip to the left, the W
+  // owned ones, two of the strip to the right), so a workgroup reads and writes whole aligned 2 KB lines as it
+  // walks down its band.  The edge columns are stored twice (by their owner and by its neighbour).
+  // The velocity snapshots are single vectors (rows kBlock apart, blocks of SBg values); in the basis the rows
+  // of all vectors are interleaved (StripMap): rows `pitch` = slots x kBlock apart, vectors kBlock apart (the
+  // `ld` the kernel is given), blocks of SB values.
+  int sm = 0, pitch = 0, SBg = 0;
+  int64_t SB = 0;
 };
 
 // The counter all compute units share (s_memrealtime), low 32 bits: only differences are used.
@@ -289,22 +292,28 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   const int ccm = cc > 0 ? cc - 1 : 0, ccp = cc + 1 < P ? cc + 1 : P - 1;
   auto rowc = [&](int r) -> int64_t { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); };  // a grid row
   auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };     // ... or a halo row
-  // position of this lane's column (and of its two neighbours) in a row of a basis vector or
-  // velocity snapshot, and the distance between rows
+  // position of this lane's column in a row of a basis vector (off) and of the lane's column and its two
+  // neighbours in a row of a velocity snapshot (goff, goffm, goffp), and the distances between rows
   const bool sm = geo.sm != 0;
-  const int pitch = sm ? kBlock : P;
-  int off = cc, offm = ccm, offp = ccp, soff = cc;
+  const int pitch = sm ? geo.pitch : P, gpitch = sm ? kBlock : P;
+  int off = cc, soff = cc, goff = cc, goffm = ccm, goffp = ccp;
   if (sm) {
-    const int base = strip * geo.SB + kBlock;             // row 0 of this strip's block
+    // the basis pointers move to this strip's block (its size does not fit 32 bits times the strip number)
+    V += (int64_t)strip * geo.SB;
+    u_in += (int64_t)strip * geo.SB;
+    u_out += (int64_t)strip * geo.SB;
+    const int base = geo.pitch;                           // row 0 of the block
     const int lt = t <= wown + 3 ? t : wown + 3;          // lanes beyond the strip repeat its last position
     off = base + lt;
-    offm = base + (lt > 0 ? lt - 1 : 0);
-    offp = base + (lt + 1 < kBlock ? lt + 1 : kBlock - 1);
+    const int gbase = strip * geo.SBg + kBlock;           // row 0 of this strip's block of a snapshot
+    goff = gbase + lt;
+    goffm = gbase + (lt > 0 ? lt - 1 : 0);
+    goffp = gbase + (lt + 1 < kBlock ? lt + 1 : kBlock - 1);
     // the outermost columns of s_NV are the only values a workgroup needs that it did not store
     // itself one step earlier: they come from their owners' blocks
     soff = off;
-    if (t == 0 && strip > 0) soff = base - geo.SB + geo.W;
-    if (t == wown + 3 && strip + 1 < geo.nstrips) soff = base + geo.SB + 3;
+    if (t == 0 && strip > 0) soff = base - (int)geo.SB + geo.W;
+    if (t == wown + 3 && strip + 1 < geo.nstrips) soff = base + (int)geo.SB + 3;
   }
   auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * pitch + soff]; };
   auto s_ok = [&](int r) -> bool {
@@ -360,10 +369,10 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {  // what the operator coefficients of row r are made of
     const int64_t ro = rowc(r) * P;
     if (GEN) {
-      const int64_t rg = rowc(r) * pitch;
-      n.b[1] = gen.v[rg + offm];
-      n.b[3] = gen.v[rg + offp];
-      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * pitch + off]);
+      const int64_t rg = rowc(r) * gpitch;
+      n.b[1] = gen.v[rg + goffm];
+      n.b[3] = gen.v[rg + goffp];
+      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * gpitch + goff]);
     } else {
       n.b[0] = __builtin_nontemporal_load(&b.w[ro + cc]);
       n.b[1] = __builtin_nontemporal_load(&b.s[ro + cc]);
@@ -379,8 +388,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
     n.s = __builtin_nontemporal_load(s_addr(r + 2));
   };
   if (GEN) {
-    gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * pitch + off]);
-    gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * pitch + off]);
+    gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * gpitch + goff]);
+    gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * gpitch + goff]);
   }
   auto issue_all = [&](Req &n, int r) __attribute__((always_inline)) {  // everything the round of row r consumes
     issue_op(n, r);
@@ -547,14 +556,14 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 // vectors.  Per lane that is half the registers, so two wavefronts fit a SIMD where the
 // kernel above runs with one, and the arithmetic of one overlaps the waiting of the other.
 constexpr int kSplitBlock = 2 * kBlock;
-constexpr int kUniformHalfUpto = 37;
+constexpr int kUniformHalfUpto = 35;
 constexpr int kSplitFrom = 18;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
 // rows stored together: as many as the LDS left beside the parked vectors holds
-constexpr int split_store_rows(int nv) { return nv <= 42 ? 32 : 16; }
+constexpr int split_store_rows(int nv) { return nv <= 40 ? 32 : 16; }
 // Vectors per half whose parked values wait in registers instead of LDS, as many as the registers
 // hold: fewer LDS round trips in the dot-product phase (2 % up to 34 earlier vectors), and the LDS
 // for 32-row bursts up to 42 earlier vectors.
-constexpr int split_park_regs(int nv) { return nv < 18 ? 0 : (nv <= 24 ? 9 : (nv <= 30 ? 8 : (nv <= 34 ? 6 : (nv <= 42 ? 4 : 0)))); }
+constexpr int split_park_regs(int nv) { return nv < 18 ? 0 : (nv <= 24 ? 9 : (nv <= 30 ? 8 : (nv <= 33 ? 6 : (nv <= 40 ? 4 : 0)))); }
 
 template <int NV, bool GEN>
 __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Bands b, BandGen gen,
@@ -608,17 +617,22 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   auto rowh = [&](int r) -> int64_t { return r < -1 ? -1 : (r > rows ? rows : r); };
   // positions within a row of a basis vector / velocity snapshot, as in k_arnoldi_fused
   const bool sm = geo.sm != 0;
-  const int pitch = sm ? kBlock : P;
-  int off = cc, offm = ccm, offp = ccp, soff = cc;
+  const int pitch = sm ? geo.pitch : P, gpitch = sm ? kBlock : P;
+  int off = cc, soff = cc, goff = cc, goffm = ccm, goffp = ccp;
   if (sm) {
-    const int base = strip * geo.SB + kBlock;
+    V += (int64_t)strip * geo.SB;
+    u_in += (int64_t)strip * geo.SB;
+    u_out += (int64_t)strip * geo.SB;
+    const int base = geo.pitch;
     const int lt = t <= wown + 3 ? t : wown + 3;
     off = base + lt;
-    offm = base + (lt > 0 ? lt - 1 : 0);
-    offp = base + (lt + 1 < kBlock ? lt + 1 : kBlock - 1);
+    const int gbase = strip * geo.SBg + kBlock;
+    goff = gbase + lt;
+    goffm = gbase + (lt > 0 ? lt - 1 : 0);
+    goffp = gbase + (lt + 1 < kBlock ? lt + 1 : kBlock - 1);
     soff = off;
-    if (t == 0 && strip > 0) soff = base - geo.SB + geo.W;
-    if (t == wown + 3 && strip + 1 < geo.nstrips) soff = base + geo.SB + 3;
+    if (t == 0 && strip > 0) soff = base - (int)geo.SB + geo.W;
+    if (t == wown + 3 && strip + 1 < geo.nstrips) soff = base + (int)geo.SB + 3;
   }
   auto s_addr = [&](int r) -> const double * { return &u_in[(s_halo ? rowh(r) : rowc(r)) * pitch + soff]; };
   auto s_ok = [&](int r) -> bool {
@@ -669,10 +683,10 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {
     const int64_t ro = rowc(r) * P;
     if (GEN) {
-      const int64_t rg = rowc(r) * pitch;
-      n.b[1] = gen.v[rg + offm];
-      n.b[3] = gen.v[rg + offp];
-      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * pitch + off]);
+      const int64_t rg = rowc(r) * gpitch;
+      n.b[1] = gen.v[rg + goffm];
+      n.b[3] = gen.v[rg + goffp];
+      n.gu = __builtin_nontemporal_load(&gen.u[rowh(r + 1) * gpitch + goff]);
     } else {
       n.b[0] = __builtin_nontemporal_load(&b.w[ro + cc]);
       n.b[1] = __builtin_nontemporal_load(&b.s[ro + cc]);
@@ -691,8 +705,8 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
     const int64_t i0 = rowc(rs - 1) * pitch + off;
     if (half == 0) {
       if (GEN) {
-        gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * pitch + off]);
-        gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * pitch + off]);
+        gu0 = __builtin_nontemporal_load(&gen.u[rowh(rs - 2) * gpitch + goff]);
+        gu1 = __builtin_nontemporal_load(&gen.u[rowh(rs - 1) * gpitch + goff]);
       }
       issue_op(qa, rs - 1);
       issue_row(qa, i0);
@@ -956,7 +970,7 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
 // strip that owns column c.
 __device__ __forceinline__ int64_t strip_pos(const StripMap &m, int r, int c) {
   const int s = c / m.W;
-  return (int64_t)s * m.SB + (int64_t)(r + 1) * kBlock + (c - s * m.W + 2);
+  return (int64_t)s * m.SB + (int64_t)(r + 1) * m.pitch + (c - s * m.W + 2);
 }
 
 // map.on: the basis vectors (V, u_in, u_out) are strip-major; the bands stay in grid order.
@@ -981,7 +995,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_close(Bands b, const double 
     const int col = (int)(i % P);
     // e: position of the unknown in a basis vector; rp: distance to the same column one grid row on
     const int64_t e = map.on ? strip_pos(map, (int)(i / P), col) : i;
-    const int64_t rp = map.on ? kBlock : P;
+    const int64_t rp = map.on ? map.pitch : P;
     double vk[NV > 0 ? NV : 1];
 #pragma unroll
     for (int k = 0; k < NV; k++) vk[k] = __builtin_nontemporal_load(&V[(int64_t)k * ld + e]);
@@ -1028,7 +1042,7 @@ __global__ __launch_bounds__(kBlock) void k_to_strips(const double *__restrict__
     const int c = s * map.W - 2 + lt;
     const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
     const bool ok = c >= 0 && c < P && lt <= wown + 3 && ((r >= 0 && r < rows) || src_halo != 0);
-    __builtin_nontemporal_store(ok ? src[(int64_t)r * P + c] : 0.0, &dst[(int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt]);
+    __builtin_nontemporal_store(ok ? src[(int64_t)r * P + c] : 0.0, &dst[(int64_t)s * map.SB + (int64_t)(r + 1) * map.pitch + lt]);
   }
 }
 
@@ -1053,7 +1067,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_to_strips(const double *__rest
     const bool ok = c >= 0 && c < P && lt <= wown + 3 && r >= 0 && r < rows;
     double v = 0.0;
     if (ok) v = __builtin_nontemporal_load(&src[(int64_t)r * P + c]) / nrm;
-    __builtin_nontemporal_store(v, &strip_dst[(int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt]);
+    __builtin_nontemporal_store(v, &strip_dst[(int64_t)s * map.SB + (int64_t)(r + 1) * map.pitch + lt]);
     if (ok && lt >= 2 && lt < wown + 2) __builtin_nontemporal_store(v, &grid_dst[(int64_t)r * P + c]);
   }
 }
@@ -1061,7 +1075,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_to_strips(const double *__rest
 // x (grid order) = sum_k y_k V_k of strip-major vectors; per element the operations of k_combine.  A
 // workgroup takes one row of one strip at a time (lane = position in the row), so every read is one
 // aligned 2 KB line.  (Lanes that move 16 bytes, two rows per workgroup, were measured slower: 5.62
-// against 5.39 ms on an 8192 x 8192 grid with 50 vectors.)
+// against 5.39 ms on an 8192 x 8192 grid with 50 vectors.)  The default is k_combine_strips_rows below.
 template <int U>
 __global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restrict__ V, int64_t ld,
                                                             const double *__restrict__ y, int m,
@@ -1082,12 +1096,58 @@ __global__ __launch_bounds__(kBlock) void k_combine_strips(const double *__restr
     const int c = s * map.W - 2 + lt;
     const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
     if (lt < 2 || lt >= wown + 2) continue;  // the strip's own columns only
-    const int64_t e = (int64_t)s * map.SB + (int64_t)(r + 1) * kBlock + lt;
+    const int64_t e = (int64_t)s * map.SB + (int64_t)(r + 1) * map.pitch + lt;
     const int64_t i = (int64_t)r * P + c;
     double acc = accumulate ? x[i] : 0.0;
 #pragma unroll U
     for (int k = 0; k < m; k++) acc = acc + ys[k] * __builtin_nontemporal_load(&V[(int64_t)k * ld + e]);
     __builtin_nontemporal_store(acc, &x[i]);
+  }
+}
+
+// The same with R consecutive rows of a strip per visit (a lane keeps R running sums): with the rows of all
+// vectors interleaved, the R rows of the m vectors a workgroup reads per visit are one contiguous piece of memory.
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_combine_strips_rows(const double *__restrict__ V, int64_t ld,
+                                                                 const double *__restrict__ y, int m,
+                                                                 double *__restrict__ x, int rows, int P,
+                                                                 const int *__restrict__ count, int accumulate,
+                                                                 const double *__restrict__ sigma, StripMap map) {
+  __shared__ double ys[kMaxM];
+  if (count != nullptr) {
+    const int c = *count;
+    if (c < m) m = c;
+  }
+  for (int i = threadIdx.x; i < m; i += kBlock) ys[i] = sigma != nullptr ? y[i] / sigma[i] : y[i];
+  __syncthreads();
+  const int lt = threadIdx.x;
+  const int groups = (rows + R - 1) / R;
+  const int64_t total = (int64_t)map.nstrips * groups;
+  for (int64_t q = blockIdx.x; q < total; q += gridDim.x) {
+    const int s = (int)(q / groups), r0 = (int)(q % groups) * R;
+    const int c = s * map.W - 2 + lt;
+    const int wown = (s + 1) * map.W <= P ? map.W : P - s * map.W;
+    const bool own = lt >= 2 && lt < wown + 2;  // the strip's own columns only
+    const int64_t e = (int64_t)s * map.SB + (int64_t)(r0 + 1) * map.pitch + lt;
+    double acc[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) acc[j] = (accumulate && own && r0 + j < rows) ? x[(int64_t)(r0 + j) * P + c] : 0.0;
+#pragma unroll 2
+    for (int k = 0; k < m; k++) {
+      const double yk = ys[k];
+      const double *vk = &V[(int64_t)k * ld + e];
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        // rows behind the last one: the row of zeros / the next strip's block, read but not used
+        const double v = __builtin_nontemporal_load(&vk[(int64_t)(r0 + j < rows ? j : 0) * map.pitch]);
+        acc[j] = acc[j] + yk * v;
+      }
+    }
+    if (own) {
+#pragma unroll
+      for (int j = 0; j < R; j++)
+        if (r0 + j < rows) __builtin_nontemporal_store(acc[j], &x[(int64_t)(r0 + j) * P + c]);
+    }
   }
 }
 
@@ -1199,6 +1259,8 @@ int store_tick(int nv) {
   }
   const int p = period.load(std::memory_order_relaxed);
   if (p >= 0) return nv >= from.load(std::memory_order_relaxed) ? p : 0;
+  // (41 to 46 earlier vectors: the sweeps with 16-row rings, re-measured with the interleaved basis)
+  if (nv >= 41) return nv <= 44 ? 4096 : (nv <= 46 ? 12288 : 8192);
   return nv <= 3 ? 0 : (nv <= 7 ? 2048 : (nv <= 12 ? 3072 : (nv <= 18 ? 4096 : (nv <= 27 ? 6144 : 8192))));
 }
 // Register sets of the 256-thread kernel for step nv (its requests run sets - 1 rows ahead).  Sweeps over few
@@ -1417,13 +1479,14 @@ int fused_parts(int rows, int cols) {
   return most;
 }
 
-StripMap strip_map(int rows, int cols) {
-  const FusedGeom g = fused_geom(rows, cols, 0);  // strips depend on the row length alone
+StripMap strip_map(int rows, int cols, int slots) {
   StripMap m;
   m.on = 1;
-  m.W = g.W;
-  m.nstrips = g.nstrips;
-  m.SB = (rows + 2) * kBlock;
+  // strips depend on the row length alone (as in fused_geom)
+  m.nstrips = (cols + kStripMax - 1) / kStripMax;
+  m.W = (cols + m.nstrips - 1) / m.nstrips;
+  m.pitch = slots * kBlock;
+  m.SB = (int64_t)(rows + 2) * m.pitch;
   return m;
 }
 
@@ -1435,21 +1498,40 @@ void launch_to_strips(hipStream_t st, const double *src, double *dst, int rows, 
 }
 
 void launch_scale_to_strips(hipStream_t st, const double *src, double *grid_dst, double *strip_dst, const double *part,
-                            int nparts, int rows, int cols, double *out) {
-  const StripMap m = strip_map(rows, cols);
+                            int nparts, int rows, int cols, int slots, double *out) {
+  const StripMap m = strip_map(rows, cols, slots);
   const int64_t total = (int64_t)m.nstrips * (rows + 2);
   hipLaunchKernelGGL(k_scale_to_strips, dim3((unsigned)(total < 2048 ? total : 2048)), dim3(kBlock), 0, st, src, grid_dst,
                      strip_dst, part, nparts, rows, cols, m, out, launch_predicate_current());
 }
 
-void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
-                           int cols, const int *count, bool accumulate, const double *sigma) {
-  const StripMap map = strip_map(rows, cols);
+void launch_combine_strips(hipStream_t st, const double *V, const double *y, int m, double *x, int rows, int cols,
+                           int slots, const int *count, bool accumulate, const double *sigma) {
+  const StripMap map = strip_map(rows, cols, slots);
+  const int64_t ld = kBlock;  // vector k starts k rows of a strip into the interleaved basis
   const int64_t total = (int64_t)map.nstrips * rows;
-  // 1024 workgroups: four per compute unit, each walking a share of the (strip, row) pairs
-  static const int grid_env = getenv("KRY_COMBINE_GRID") ? atoi(getenv("KRY_COMBINE_GRID")) : 1024;
+  // Sixteen rows of a strip per visit and one workgroup per compute unit, measured on an 8192 x 8192 grid with 50
+  // vectors (KRY_COMBINE_ROWS x KRY_COMBINE_GRID): 1 x 1024 (one row per visit) 5.40 ms, 4 x 1024 5.22, 8 x 1024
+  // 5.08, 16 x 1024 4.94, 8 x 256 4.85, 16 x 256 4.70 (5.83 TB/s), 16 x 128 6.70, 16 x 384 5.40, 32 rows: spills.
+  static const int rows_env = getenv("KRY_COMBINE_ROWS") ? atoi(getenv("KRY_COMBINE_ROWS")) : 16;
+  static const int grid_env = getenv("KRY_COMBINE_GRID") ? atoi(getenv("KRY_COMBINE_GRID")) : (rows_env > 1 ? 256 : 1024);
   static const int unroll_env = getenv("KRY_COMBINE_UNROLL") ? atoi(getenv("KRY_COMBINE_UNROLL")) : 8;
   const unsigned grid = (unsigned)(total < grid_env ? total : grid_env);
+  if (rows_env == 4 || rows_env == 8 || rows_env == 16) {
+    const int64_t tot = (int64_t)map.nstrips * ((rows + rows_env - 1) / rows_env);
+    const unsigned gr = (unsigned)(tot < grid_env ? tot : grid_env);
+    if (rows_env == 4)
+      hipLaunchKernelGGL(k_combine_strips_rows<4>, dim3(gr), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
+                         accumulate ? 1 : 0, sigma, map);
+    else if (rows_env == 8)
+      hipLaunchKernelGGL(k_combine_strips_rows<8>, dim3(gr), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
+                         accumulate ? 1 : 0, sigma, map);
+
+    else
+      hipLaunchKernelGGL(k_combine_strips_rows<16>, dim3(gr), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
+                         accumulate ? 1 : 0, sigma, map);
+    return;
+  }
   if (unroll_env >= 16)
     hipLaunchKernelGGL(k_combine_strips<16>, dim3(grid), dim3(kBlock), 0, st, V, ld, y, m, x, rows, cols, count,
                        accumulate ? 1 : 0, sigma, map);
@@ -1461,19 +1543,22 @@ void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const do
                        accumulate ? 1 : 0, sigma, map);
 }
 
-void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols) {
+void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols,
+                           int slots) {
   const int64_t n = (int64_t)rows * cols;
   hipLaunchKernelGGL(k_unscale_strips, dim3(grid_for(n)), dim3(kBlock), 0, st, src, sigma, k, dst, n, cols,
-                     strip_map(rows, cols));
+                     strip_map(rows, cols, slots));
 }
 
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo, const BandGen *gen, int which,
-                          bool strip_major, const CoefIn *cin) {
+                          int sm_slots, const CoefIn *cin) {
   FusedGeom g = fused_geom(rows, cols, nv);
-  if (strip_major) {
+  if (sm_slots > 0) {
     g.sm = 1;
-    g.SB = (rows + 2) * kBlock;
+    g.pitch = sm_slots * kBlock;
+    g.SB = (int64_t)(rows + 2) * g.pitch;
+    g.SBg = (rows + 2) * kBlock;
   }
   *nparts = g.nstrips * g.nbands;
   int launch_bands = g.nbands;

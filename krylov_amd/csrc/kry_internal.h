@@ -46,10 +46,18 @@ struct BandGen {
 
 // Strip-major storage of a vector on a rows x cols grid: the columns are cut into nstrips strips of W
 // owned columns (the strips the one-sweep kernels' workgroups walk), and strip s is stored as a block of
-// SB = (rows + 2) x kBlock values -- a grid row in front, the rows, one behind; position t of a row holds
+// (rows + 2) rows of kBlock values -- a grid row in front, the rows, one behind; position t of a row holds
 // column s W - 2 + t, so the two columns next to a strip on either side are stored twice.
+// A single vector (the velocity snapshots): rows follow each other at a pitch of kBlock values, SB = (rows + 2)
+// x kBlock.  The Krylov basis: the rows of ALL its vectors are interleaved -- row r of vector 0, row r of vector
+// 1, ... (slots of them), then row r + 1 -- so pitch = slots x kBlock, SB = (rows + 2) x pitch, and vector k
+// starts k x kBlock values into the array.  A workgroup that walks down its strip then reads, per row, ONE
+// contiguous piece holding that row of every vector (instead of one 2 KB piece per vector, each in a different
+// memory page: with more than about thirty vectors that overflowed the translation caches of the compute units,
+// 2 % of the translations missed from 29 earlier vectors on, next to none below).
 struct StripMap {
-  int on = 0, W = 0, SB = 0, nstrips = 0;
+  int on = 0, W = 0, nstrips = 0, pitch = 0;
+  int64_t SB = 0;
 };
 
 // Device-resident state of the restarted solver with residual monitor.
@@ -209,26 +217,32 @@ struct CoefIn {
   int m = 0;
   double *sigma = nullptr;
 };
-// strip_major (with gen only): the basis vectors and gen's velocity snapshots are strip-major (StripMap).
+// sm_slots > 0: the basis is strip-major with the rows of sm_slots vectors interleaved (V: vector 0, ld = kBlock)
+// and gen's velocity snapshots are strip-major single vectors (StripMap).
 void launch_arnoldi_fused(hipStream_t st, int nv, int rows, int cols, const Bands &b, const double *V, int64_t ld,
                           const double *coef, double *part, int *nparts, bool has_halo,
-                          const BandGen *gen = nullptr, int which = kSweepAll, bool strip_major = false,
+                          const BandGen *gen = nullptr, int which = kSweepAll, int sm_slots = 0,
                           const CoefIn *cin = nullptr);
-// The strip-major layout of vectors on a rows x cols grid, and its size in doubles.
-StripMap strip_map(int rows, int cols);
+// The strip-major layout of a vector on a rows x cols grid (slots = 1), or of a basis of `slots` vectors with
+// interleaved rows, and the size of one vector's share of it in doubles.
+StripMap strip_map(int rows, int cols, int slots = 1);
 inline int64_t strip_major_size(int rows, int cols) {
   const StripMap m = strip_map(rows, cols);
   return (int64_t)m.nstrips * m.SB;
 }
-// dst (strip-major) = src (grid order; src_has_halo_rows: with a grid row in front and behind, which are copied too)
+// dst (strip-major single vector) = src (grid order; src_has_halo_rows: with a grid row in front and behind, which
+// are copied too)
 void launch_to_strips(hipStream_t st, const double *src, double *dst, int rows, int cols, bool src_has_halo_rows);
-// src / sqrt(sum(part)) in one pass, stored in grid order (grid_dst) and strip-major (strip_dst); *out = the norm
+// src / sqrt(sum(part)) in one pass, stored in grid order (grid_dst) and as vector 0 of a strip-major basis of
+// `slots` interleaved vectors (strip_dst); *out = the norm
 void launch_scale_to_strips(hipStream_t st, const double *src, double *grid_dst, double *strip_dst, const double *part,
-                            int nparts, int rows, int cols, double *out);
-// launch_combine / launch_unscale for strip-major basis vectors; x and dst are in grid order
-void launch_combine_strips(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x, int rows,
-                           int cols, const int *count, bool accumulate, const double *sigma);
-void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols);
+                            int nparts, int rows, int cols, int slots, double *out);
+// launch_combine / launch_unscale for the vectors of a strip-major basis of `slots` interleaved vectors (V: vector
+// 0; src: the vector itself); x and dst are in grid order
+void launch_combine_strips(hipStream_t st, const double *V, const double *y, int m, double *x, int rows, int cols,
+                           int slots, const int *count, bool accumulate, const double *sigma);
+void launch_unscale_strips(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int rows, int cols,
+                           int slots);
 bool fused_bands_splittable(int nv, int rows, int cols);
 // Whether the sweep of step nv delivers <t, t> as its last partial sum (2 nv + 5 sums instead of 2 nv + 4).
 bool fused_sweep_has_tt(int nv);
