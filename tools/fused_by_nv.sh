@@ -11,7 +11,7 @@ import csv, glob, re
 f = glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
-    m = re.search(r"k_arnoldi_(?:fused|roll|split)<(\d+), *(true|false|\(bool\)[01])>", r["Name"])
+    m = re.search(r"k_arnoldi_(?:fused|roll|split)<(\d+), *(true|false|\(bool\)[01])", r["Name"])
     if m:
         rows.append((int(m.group(1)), float(r["AverageNs"]) / 1e3, int(r["Calls"]), m.group(2) in ("true", "(bool)1")))
 N = 8.0 * 8194 * 8194

@@ -14,5 +14,5 @@ $B --extended 1e-8 --steps 2 --warmup 1 > $OUT/extended_s_iso_rtol1e-8.json 2> $
 for f in $OUT/*.json; do python3 -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[-1])
-print('$f'.split('/')[-1], round(d['value'],1), 'it/s', round(d['ms_per_step'],2), 'ms/step', d.get('roofline',{}).get('frac'), d['config'].get('basis_strip_major'))
+print('$f'.split('/')[-1], round(d['value'],1), 'it/s', round(d['ms_per_step'],2), 'ms/step', (d.get('roofline') or {}).get('frac'), d['config'].get('basis_strip_major'))
 "; done

@@ -12,7 +12,7 @@ import json, re
 d = json.load(open("$OUT/pass1.json"))
 rows = []
 for name, c in d.items():
-    m = re.search(r"k_arnoldi_(?:fused|split)<(\d+), *(true|false|\(bool\)[01])>", name)
+    m = re.search(r"k_arnoldi_(?:fused|split)<(\d+), *(true|false|\(bool\)[01])", name)
     if not m:
         continue
     g = lambda k: c[k]["mean"]
