@@ -275,6 +275,17 @@ struct kry_gmres {
   int grid_rows = 0, grid_cols = 0;
   bool strips_capable = false, strips = false;
   double *v0 = nullptr;
+  // cil: the current basis is chunk-interleaved (il1 in kry_device.h): solves on one rank whose every step is a
+  // step of the Gram-Schmidt chain.  The newest vector is then kept contiguous as well, in v0, for the kernels
+  // that take it as their operand (operator, line preconditioner).
+  bool cil_capable = false, cil = false;
+  // Between two chain steps of a fixed cycle with the line preconditioner: w holds the next basis vector
+  // un-normalised and pend_part the partial sums of its squares; the preconditioner kernel of the next step
+  // normalises it on the way in (k_tdp_apply2 with SC) instead of a pass of its own.
+  bool scale_pending = false;
+  bool fuse_scale = true;  // environment KRY_TDP_FUSE_SCALE=0 when the solver is created: off
+  const double *pend_part = nullptr;
+  int pend_np = 0;
   // The norm of a cycle's last vector from the last sweep's sums (launch_fused_coeffs) instead of from the
   // closing kernel: for solves with the operator the solver is bound to (bound_op: the operator of the step
   // object that owns the solver, which lives as long as the solver does), because the vector itself is then
@@ -291,13 +302,16 @@ struct kry_gmres {
 // therefore stale after a captured step is replayed if something else used the solver in between.
 struct BasisState {
   int nvec = 0;
-  bool scaled = false, strips = false, last_pending = false;
+  bool scaled = false, strips = false, last_pending = false, cil = false;
 };
-static BasisState basis_state(const kry_gmres *g) { return BasisState{g->nvec, g->scaled, g->strips, g->last_pending}; }
+static BasisState basis_state(const kry_gmres *g) {
+  return BasisState{g->nvec, g->scaled, g->strips, g->last_pending, g->cil};
+}
 static void set_basis_state(kry_gmres *g, const BasisState &b) {
   g->nvec = b.nvec;
   g->scaled = b.scaled;
   g->strips = b.strips;
+  g->cil = b.cil;
   g->last_pending = b.last_pending;
 }
 
@@ -785,7 +799,7 @@ int64_t kry_op_size(const kry_op *op) { return op ? op->n : 0; }
 
 // y = A x; with kc > 0 also the partial sums of the first Gram-Schmidt group
 static void op_apply_async(kry_op *op, const double *x, double *y, int kc, const double *cbase,
-                           int64_t ld, double *part, int *nparts, bool x_has_halo) {
+                           int64_t ld, double *part, int *nparts, bool x_has_halo, int64_t pitch = 0) {
   hipStream_t st = op->ctx->stream;
   if (op->kind == 0) {
     Bands b{op->band[0], op->band[1], op->band[2], op->band[3], op->band[4]};
@@ -798,9 +812,9 @@ static void op_apply_async(kry_op *op, const double *x, double *y, int kc, const
     // KRY_SPMV_GEN=k: from k partners on (0: never).
     static const int gen_min_kc = getenv("KRY_SPMV_GEN") ? atoi(getenv("KRY_SPMV_GEN")) : 4;
     const BandGen *gen = (gen_min_kc > 0 && kc >= gen_min_kc && op->has_gen && op->use_gen) ? &op->gen : nullptr;
-    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts, x_has_halo, gen);
+    launch_spmv_stencil(st, b, op->n, op->cols, x, y, kc, cbase, ld, part, nparts, x_has_halo, gen, pitch);
   } else {
-    launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, kc, cbase, ld, part, nparts);
+    launch_spmv_csr(st, op->rowptr, op->col, op->val, op->n, x, y, kc, cbase, ld, part, nparts, pitch);
   }
 }
 
@@ -842,6 +856,11 @@ static double *basis(kry_gmres *g, int i) { return g->V + (int64_t)i * g->ld + g
 // Vector i of a strip-major basis (StripMap): the rows of the m + 1 vectors are interleaved, vector i starts i rows
 // of a strip into the array.
 static double *strip_vec(kry_gmres *g, int i) { return g->V + g->halo + (int64_t)i * kBlock; }
+// Vector i as the chain's kernels address it, the distance between two vectors and between two chunks of one
+// vector (0: contiguous vectors)
+static double *chain_vec(kry_gmres *g, int i) { return g->cil ? g->V + g->halo + (int64_t)i * kChunk : basis(g, i); }
+static int64_t chain_ld(const kry_gmres *g) { return g->cil ? (int64_t)kChunk : g->ld; }
+static int64_t chain_pitch(const kry_gmres *g) { return g->cil ? (int64_t)(g->m + 1) * kChunk : 0; }
 
 // Latest step at which the one-sweep kernels can take over: the hand-over applies the
 // operator with the dots of all earlier vectors in one kernel (at most kMgsBlock of
@@ -874,6 +893,12 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   g->halo = (halo_row + 31) / 32 * 32;
   // 256-byte multiples: every vector starts 16-byte aligned, halo included
   g->ld = g->halo + (n + 31) / 32 * 32 + g->halo;
+  if (ctx->nranks == 1 && !(getenv("KRY_CHAIN_INTERLEAVE") && atoi(getenv("KRY_CHAIN_INTERLEAVE")) == 0)) {
+    // whole chunks, so that the m + 1 vectors fit the same array chunk-interleaved
+    g->cil_capable = true;
+    g->ld = g->halo + (n + kChunk - 1) / kChunk * kChunk + g->halo;
+  }
+  if (getenv("KRY_TDP_FUSE_SCALE") && atoi(getenv("KRY_TDP_FUSE_SCALE")) == 0) g->fuse_scale = false;  // experimentation knob
   g->m = m;
   g->flags = flags;
   const bool one_sweep_possible = !(flags & KRY_GMRES_TDP) && m <= kFusedMaxM && m >= 3;
@@ -925,7 +950,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
     if (st == KRY_OK) st = dev_alloc(&g->dd, g->ld);
     if (st == KRY_OK) st = dev_alloc(&g->ud, g->ld);
   }
-  if (st == KRY_OK && g->strips_capable) st = dev_alloc(&g->v0, g->ld);
+  if (st == KRY_OK && (g->strips_capable || g->cil_capable)) st = dev_alloc(&g->v0, g->ld);
   if (st == KRY_OK && one_sweep_possible) {
     // hand-over from the chain: after two steps, or at once where the basis can be strip-major
     int from = g->strips_capable ? 0 : 2;
@@ -1060,6 +1085,7 @@ static int fused_first(const kry_gmres *g) {
 int kry_gmres_get_one_sweep(const kry_gmres *g) { return g && g->fparts ? fused_first(g) : -1; }
 
 int kry_gmres_basis_strip_major(const kry_gmres *g) { return g && g->strips ? 1 : 0; }
+int kry_gmres_basis_chunk_interleaved(const kry_gmres *g) { return g && g->cil ? 1 : 0; }
 
 int kry_gmres_set_tolerance(kry_gmres *g, double rtol, int max_cycles) {
   if (!g) return fail(KRY_ERR_INVALID, "NULL argument");
@@ -1142,7 +1168,7 @@ static void store_v0(kry_gmres *g, const double *src, const double *part, int np
   if (g->strips) {
     launch_scale_to_strips(st, src, g->v0, strip_vec(g, 0), part, np, g->grid_rows, g->grid_cols, g->m + 1, out);
   } else {
-    launch_scale_from(st, src, basis(g, 0), part, np, g->n, out);
+    launch_scale_from(st, src, chain_vec(g, 0), part, np, g->n, out, chain_pitch(g), g->cil ? g->v0 : nullptr);
   }
 }
 
@@ -1159,6 +1185,7 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
   g->nvec = 1;
   g->scaled = false;
   g->last_pending = false;
+  g->scale_pending = false;
   // Every vector starts a cycle normalised; the one-sweep steps overwrite the scale factors
   // of the slots they fill.  A monitored solve may stop before they run (their kernels,
   // the hand-over included, are predicated), so there the factors are reset here; a fixed
@@ -1170,7 +1197,16 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
 // One Arnoldi step with the fused modified Gram-Schmidt chain.  In the
 // restarted solver every kernel of the step is predicated on the device flag
 // that the residual monitor raises.
-static int arnoldi_async(kry_gmres *g, kry_op *op) {
+// Whether the chain steps of a fixed cycle leave the normalisation of their vector to the next step's
+// preconditioner kernel
+static bool tdp_fuses_scale(const kry_gmres *g) {
+  return g->fuse_scale && (g->flags & KRY_GMRES_TDP) && !(g->flags & KRY_GMRES_EXTENDED) && g->tdp_ready && g->nlines * g->L == g->n &&
+         tdp_scaled_supported(g->lo, g->dd, g->ud, g->w, g->z, g->V + g->halo, g->nlines, g->L);
+}
+
+// another_follows: the caller queues the next chain step of the same cycle right behind this one (the
+// normalisation of this step's vector may then be left to that step's preconditioner kernel).
+static int arnoldi_async(kry_gmres *g, kry_op *op, bool another_follows = false) {
   LaunchPredicate pred((g->flags & KRY_GMRES_EXTENDED) && g->ext ? &g->ext->stop : nullptr);
   if (g->nvec < 1) return fail(KRY_ERR_STATE, "add_arnoldi before initial_subspace");
   const int j = g->nvec - 1;
@@ -1179,11 +1215,23 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   const int64_t n = g->n;
   double *part[2] = {g->parts, g->parts + (int64_t)kMaxRed * kMaxParts};
   int np[2] = {0, 0};
-  const double *src = basis(g, j);
+  const double *src = g->cil ? g->v0 : basis(g, j);
   if (g->flags & KRY_GMRES_TDP) {
     if (!g->tdp_ready) return fail(KRY_ERR_STATE, "preconditioner has not been assembled");
     ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
-    launch_tdp_apply(st, g->lo, g->dd, g->ud, src, g->z, g->nlines, g->L);
+    if (g->scale_pending) {
+      // v_j = w / ||w||, H(j, j-1) = ||w|| and z = M^-1 v_j in one kernel
+      TdpScale sc;
+      sc.part = g->pend_part;
+      sc.np = g->pend_np;
+      sc.vout = chain_vec(g, j);
+      sc.pitch = chain_pitch(g);
+      sc.nout = g->H + (int64_t)j * g->m + (j - 1);
+      launch_tdp_apply_scaled(st, g->lo, g->dd, g->ud, g->w, g->z, g->nlines, g->L, sc);
+      g->scale_pending = false;
+    } else {
+      launch_tdp_apply(st, g->lo, g->dd, g->ud, src, g->z, g->nlines, g->L);
+    }
     src = g->z;
   }
   // Orthogonalise against v_0..v_j in groups of up to K vectors (modified
@@ -1195,7 +1243,7 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   {
     // w = A v_j fused with the dots of the first group
     ScopedKernelTimer t(g->ctx, KRY_K_SPMV);
-    op_apply_async(op, src, g->w, kp, basis(g, 0), g->ld, part[0], &np[0], g->halo_row > 0);
+    op_apply_async(op, src, g->w, kp, chain_vec(g, 0), chain_ld(g), part[0], &np[0], g->halo_row > 0, chain_pitch(g));
   }
   const double *pin = part[0];
   int npin = np[0];
@@ -1205,8 +1253,8 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
     const int kc = nv - cs < K ? nv - cs : K;
     {
       ScopedKernelTimer t(g->ctx, (kp == K && kc == K) ? KRY_K_MGS : KRY_K_MGS_PART);
-      launch_mgs_block(st, kp, kc, g->w, basis(g, ps), basis(g, cs), g->ld, pin, npin, part[cur & 1],
-                       &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n, g->G, g->m + 1, ps);
+      launch_mgs_block(st, kp, kc, g->w, chain_vec(g, ps), chain_vec(g, cs), chain_ld(g), pin, npin, part[cur & 1],
+                       &np[cur & 1], g->H + (int64_t)ps * g->m + j, g->m, n, g->G, g->m + 1, ps, chain_pitch(g));
     }
     pin = part[cur & 1];
     npin = np[cur & 1];
@@ -1216,15 +1264,20 @@ static int arnoldi_async(kry_gmres *g, kry_op *op) {
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_MGS_LAST);
-    launch_mgs_block(st, kp, 0, g->w, basis(g, ps), nullptr, g->ld, pin, npin, part[cur & 1], &np[cur & 1],
-                     g->H + (int64_t)ps * g->m + j, g->m, n, g->G, g->m + 1, ps);
+    launch_mgs_block(st, kp, 0, g->w, chain_vec(g, ps), nullptr, chain_ld(g), pin, npin, part[cur & 1], &np[cur & 1],
+                     g->H + (int64_t)ps * g->m + j, g->m, n, g->G, g->m + 1, ps, chain_pitch(g));
   }
   pin = part[cur & 1];
   npin = np[cur & 1];
   KCHK(finish_parts(g, &pin, 1, &npin));
-  {
+  if (another_follows && j + 1 < g->m && tdp_fuses_scale(g)) {
+    g->scale_pending = true;
+    g->pend_part = pin;
+    g->pend_np = npin;
+  } else {
     ScopedKernelTimer t(g->ctx, KRY_K_NORMALIZE);
-    launch_scale_from(st, g->w, basis(g, j + 1), pin, npin, n, g->H + (int64_t)(j + 1) * g->m + j);
+    launch_scale_from(st, g->w, chain_vec(g, j + 1), pin, npin, n, g->H + (int64_t)(j + 1) * g->m + j, chain_pitch(g),
+                      g->cil ? g->v0 : nullptr);
   }
   g->nvec++;
   return launch_ok("add_arnoldi");
@@ -1245,6 +1298,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
   double *R = g->R, *cs = R + (int64_t)(m + 1) * m, *sn = cs + m, *gv = sn + m;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   g->strips = strips_usable(g, op);
+  g->cil = g->cil_capable && !fused_usable(g, op);
   HIPCHK(hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)n, st));
   g->last_iters = 0;
   g->last_cycles = 0;
@@ -1291,7 +1345,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
       // x += M^-1 (V y)
       {
         ScopedKernelTimer t(g->ctx, KRY_K_COMBINE);
-        launch_combine(st, basis(g, 0), g->ld, g->y, m, g->w, n, &g->ext->iters, false);
+        launch_combine(st, chain_vec(g, 0), chain_ld(g), g->y, m, g->w, n, &g->ext->iters, false, nullptr, chain_pitch(g));
       }
       {
         ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
@@ -1305,8 +1359,8 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
         launch_combine_strips(st, strip_vec(g, 0), g->y, m, g->vars, g->grid_rows, g->grid_cols, m + 1, &g->ext->iters, true,
                               g->scaled ? g->fsigma : nullptr);
       else
-        launch_combine(st, basis(g, 0), g->ld, g->y, m, g->vars, n, &g->ext->iters, true,
-                       g->scaled ? g->fsigma : nullptr);
+        launch_combine(st, chain_vec(g, 0), chain_ld(g), g->y, m, g->vars, n, &g->ext->iters, true,
+                       g->scaled ? g->fsigma : nullptr, chain_pitch(g));
     }
     KCHK(launch_ok("extended solve"));
     HIPCHK(hipMemcpyAsync(g->ext_h, g->ext, sizeof(ExtState), hipMemcpyDeviceToHost, st));
@@ -1469,13 +1523,14 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   hipStream_t st = g->ctx->stream;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   g->strips = strips_usable(g, op);
+  g->cil = g->cil_capable && !fused_usable(g, op);
   KCHK(initial_subspace_async(g, b_dev));
   HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
   if (fused_usable(g, op)) {
     for (int i = 0; i < fused_first(g); i++) KCHK(arnoldi_async(g, op));
     KCHK(fused_steps_async(g, op));
   } else {
-    for (int i = 0; i < g->m; i++) KCHK(arnoldi_async(g, op));
+    for (int i = 0; i < g->m; i++) KCHK(arnoldi_async(g, op, i + 1 < g->m));
   }
   {
     ScopedKernelTimer t(g->ctx, KRY_K_OTHER);
@@ -1487,8 +1542,8 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
       launch_combine_strips(st, strip_vec(g, 0), g->y, g->m, g->vars, g->grid_rows, g->grid_cols, g->m + 1, nullptr, false,
                             g->scaled ? g->fsigma : nullptr);
     else
-      launch_combine(st, basis(g, 0), g->ld, g->y, g->m, g->vars, g->n, nullptr, false,
-                     g->scaled ? g->fsigma : nullptr);
+      launch_combine(st, chain_vec(g, 0), chain_ld(g), g->y, g->m, g->vars, g->n, nullptr, false,
+                     g->scaled ? g->fsigma : nullptr, chain_pitch(g));
   }
   if ((g->flags & KRY_GMRES_TDP) && (g->flags & KRY_GMRES_FIXED_PRECOND)) {
     ScopedKernelTimer t(g->ctx, KRY_K_PRECOND);
@@ -1511,7 +1566,8 @@ int kry_gmres_initial_subspace(kry_gmres *g, const double *b_host, double *beta)
   if (!g || !b_host) return fail(KRY_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(g->ctx->device));
   KCHK(stage_rhs(g, b_host));
-  g->strips = false;  // the step-wise interface works on the chain's layout
+  g->strips = false;  // the step-wise interface works on the chain's layout, with contiguous vectors
+  g->cil = false;
   KCHK(initial_subspace_async(g, g->bbuf));
   double b = 0.0;
   HIPCHK(hipMemcpyAsync(&b, g->beta, sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
@@ -1602,6 +1658,10 @@ int kry_gmres_subspace_vector(kry_gmres *g, int i, double *out_host) {
   if (g->strips) {
     launch_unscale_strips(g->ctx->stream, strip_vec(g, i), g->scaled ? g->fsigma : nullptr, i, g->w, g->grid_rows, g->grid_cols,
                           g->m + 1);
+    KCHK(launch_ok("kry_gmres_subspace_vector"));
+    src = g->w;
+  } else if (g->cil) {
+    launch_unscale(g->ctx->stream, chain_vec(g, i), nullptr, i, g->w, g->n, chain_pitch(g));
     KCHK(launch_ok("kry_gmres_subspace_vector"));
     src = g->w;
   } else if (g->scaled) {
@@ -1709,15 +1769,17 @@ int kry_gmres_cycle_bytes(const kry_gmres *g, const kry_op *op, double bytes[KRY
     launches[KRY_K_MGS_LAST] += 1;
   }
   // one normalisation per chain step (none after the one-sweep steps) + ||b|| and v_0 = b/||b||
-  bytes[KRY_K_NORMALIZE] = 2.0 * N * chain_steps + 3.0 * N;
-  launches[KRY_K_NORMALIZE] = chain_steps + 2;
+  // (with the line preconditioner, all but the last step's is done by the next step's preconditioner kernel)
+  const int fused_scales = (!fused && tdp_fuses_scale(g)) ? m - 1 : 0;
+  bytes[KRY_K_NORMALIZE] = 2.0 * N * (chain_steps - fused_scales) + 3.0 * N;
+  launches[KRY_K_NORMALIZE] = chain_steps - fused_scales + 2;
   bytes[KRY_K_COMBINE] = (m + 1) * N;
   launches[KRY_K_COMBINE] = 1;
   if (g->flags & KRY_GMRES_TDP) {
     // factor: lo,di,up read, dd,ud written; apply: forward sweep reads sol,lo,dd and writes out,
     // backward sweep reads out,ud and writes out
     const int applies = m + ((g->flags & KRY_GMRES_FIXED_PRECOND) ? 1 : 0);
-    bytes[KRY_K_PRECOND] = 5.0 * N + applies * 7.0 * N;
+    bytes[KRY_K_PRECOND] = 5.0 * N + applies * 7.0 * N + fused_scales * N;  // + the normalised vector written
     launches[KRY_K_PRECOND] = applies + 1;
   }
   return KRY_OK;

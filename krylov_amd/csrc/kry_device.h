@@ -41,6 +41,19 @@ __device__ __forceinline__ double sum_parts(const double *__restrict__ part, int
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// Chunk-interleaved basis (the Gram-Schmidt chain on one rank): the vectors are cut into chunks of kChunk values
+// and chunk c of vector 0, chunk c of vector 1, ... follow each other in memory, so that a sweep over many
+// vectors reads ONE contiguous piece per chunk instead of one piece per vector, each in a different memory page
+// (more than about thirty pages in rotation overflow the translation caches of a compute unit).  Vector k starts
+// k x kChunk values into the array; `pitch` is the distance between two chunks of one vector (slots x kChunk),
+// 0 for vectors that are contiguous.  il1 / il2: position of value i / of 16-byte element i2 within its vector.
+__device__ __forceinline__ int64_t il1(int64_t i, int64_t pitch) {
+  return pitch ? (i / kChunk) * pitch + (i % kChunk) : i;
+}
+__device__ __forceinline__ int64_t il2(int64_t i2, int64_t pitch) {
+  return pitch ? (i2 / (kChunk / 2)) * (pitch / 2) + (i2 % (kChunk / 2)) : i2;
+}
+
 __device__ __forceinline__ d2 ld_nt(const d2 *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_nt(d2 v, d2 *p) { __builtin_nontemporal_store(v, p); }
 

@@ -1198,12 +1198,18 @@ __global__ __launch_bounds__(64) void k_fused_finish(const double *__restrict__ 
   }
 }
 
-// dst = src / sigma[k] (true division, as normalize() in include/matrix.hpp:54-60)
+// dst = src / sigma[k] (true division, as normalize() in include/matrix.hpp:54-60); without sigma a plain copy.
+// pitch != 0: src is a vector of a chunk-interleaved basis.
 __global__ __launch_bounds__(kBlock) void k_unscale(const double *__restrict__ src, const double *__restrict__ sigma,
-                                                     int k, double *__restrict__ dst, int64_t n) {
+                                                     int k, double *__restrict__ dst, int64_t n, int64_t pitch) {
+  if (sigma == nullptr) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+      dst[i] = src[il1(i, pitch)];
+    return;
+  }
   const double sg = sigma[k];
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    dst[i] = src[i] / sg;
+    dst[i] = src[il1(i, pitch)] / sg;
 }
 
 // first step served by the 512-thread kernel (set_split_from, else env KRY_SPLIT_FROM, else
@@ -1603,8 +1609,9 @@ void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, do
   hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(64), 0, st, tot, m, H, sigma, launch_predicate_current(), skip);
 }
 
-void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n) {
-  hipLaunchKernelGGL(k_unscale, dim3(grid_for(n)), dim3(kBlock), 0, st, src, sigma, k, dst, n);
+void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n,
+                    int64_t pitch) {
+  hipLaunchKernelGGL(k_unscale, dim3(grid_for(n)), dim3(kBlock), 0, st, src, sigma, k, dst, n, pitch);
 }
 
 }  // namespace kry

@@ -15,6 +15,7 @@ constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups
 constexpr int kMaxParts = 2048;    // partial sums per reduction buffer
 constexpr int kMaxM = 256;         // largest Krylov dimension supported
+constexpr int kChunk = 512;        // values per chunk of a chunk-interleaved basis (see il1 in kry_device.h)
 constexpr int kMgsBlock = 32;      // most Gram-Schmidt links fused into one sweep over w
 constexpr int kMaxRed = 2 * kMgsBlock - 1;  // partial-sum arrays per pass: dots + Gram column of the last vector
 constexpr int kFusedMaxM = 50;     // largest Krylov dimension served by the one-sweep Arnoldi step
@@ -117,8 +118,9 @@ int grid_for(int64_t items);
 // part[b] = sum over block b of x[k]^2
 void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, int *nparts);
 // nrm = sqrt(sum(part)); dst = src / nrm; *out = nrm
+// pitch != 0: dst is a vector of a chunk-interleaved basis (il1); dst2 != nullptr: a second, contiguous copy
 void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
-                       int nparts, int64_t n, double *out);
+                       int nparts, int64_t n, double *out, int64_t pitch = 0, double *dst2 = nullptr);
 
 // y = A x; with kc > 0 also the partial sums of <y, c_k> and <c_a, c_{kc-1}> for the
 // kc vectors cbase + k*ld (layout: part[q * nparts + workgroup], dots first)
@@ -126,12 +128,13 @@ void launch_scale_from(hipStream_t st, const double *src, double *dst, const dou
 // instead of being read (grid-order velocity snapshots with a grid row in front and behind)
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                          double *y, int kc, const double *cbase, int64_t ld, double *part,
-                         int *nparts, bool x_has_halo, const BandGen *gen = nullptr);
+                         int *nparts, bool x_has_halo, const BandGen *gen = nullptr, int64_t pitch = 0);
 // tot[q] = sum_i part[q * np + i], q < nq (one workgroup)
 void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot);
+// (pitch, here and below: the partner vectors cbase + k ld belong to a chunk-interleaved basis)
 void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
                      int64_t n, const double *x, double *y, int kc, const double *cbase, int64_t ld,
-                     double *part, int *nparts);
+                     double *part, int *nparts, int64_t pitch = 0);
 
 // One blocked Gram-Schmidt sweep: finish the kp coefficients of the previous
 // group (pbase, pbase+ld, ...; basis vectors gp .. gp+kp-1) from part_in and the
@@ -144,7 +147,7 @@ bool mgs_block_supported(int k);
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
                       double *part_out, int *np_out, double *hout, int hstride, int64_t n, double *G,
-                      int gld, int gp);
+                      int gld, int gp, int64_t pitch = 0);
 
 // y = argmin ||beta e1 - H y|| through the normal equations and an un-pivoted
 // Doolittle LU, in the reference's loop order.  work: 3*m*m + 2*m doubles.
@@ -155,7 +158,7 @@ void launch_small_solve(hipStream_t st, const double *H, const double *beta, int
 // sigma != nullptr: V[i] holds sigma[i] times the i-th vector, y[i] is divided by sigma[i] first
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m,
                     double *x, int64_t n, const int *count = nullptr, bool accumulate = false,
-                    const double *sigma = nullptr);
+                    const double *sigma = nullptr, int64_t pitch = 0);
 // x += w
 void launch_add(hipStream_t st, double *x, const double *w, int64_t n);
 // out = a - b; part[b] = sum over block b of out[k]^2 (out may be b)
@@ -176,6 +179,20 @@ void launch_tdp_factor(hipStream_t st, const double *lo, const double *di, const
                        double *dd, double *ud, int64_t nlines, int64_t L);
 void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const double *ud,
                       const double *sol, double *out, int64_t nlines, int64_t L);
+// The same solve of sol / nrm, nrm = sqrt(sum of part[0 .. np)), which also stores that normalised vector to vout
+// (pitch != 0: as a vector of a chunk-interleaved basis) and nrm to *nout: k_scale_from and the solve in one
+// pass.  tdp_scaled_supported: whether the 16-byte-lane kernel that offers it serves these arrays.
+struct TdpScale {
+  const double *part = nullptr;
+  int np = 0;
+  double *vout = nullptr;
+  int64_t pitch = 0;
+  double *nout = nullptr;
+};
+bool tdp_scaled_supported(const double *lo, const double *dd, const double *ud, const double *sol, const double *out,
+                          const double *vout, int64_t nlines, int64_t L);
+void launch_tdp_apply_scaled(hipStream_t st, const double *lo, const double *dd, const double *ud, const double *sol,
+                             double *out, int64_t nlines, int64_t L, const TdpScale &sc);
 // lo/di/up[k] = A(k,k-1), A(k,k), A(k,k+1) of a CSR matrix (0 where absent)
 void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col,
                             const double *val, int64_t n, double *lo, double *di, double *up);
@@ -272,8 +289,9 @@ void launch_fused_coeffs(hipStream_t st, const double *tot, int i, bool boot, do
 // sigma[m] = sqrt(tot[0]), H[m][m-1] = sigma[m]
 void launch_fused_finish(hipStream_t st, const double *tot, int m, double *H, double *sigma,
                          const int *skip = nullptr);
-// dst = src / sigma[k]
-void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n);
+// dst = src / sigma[k] (sigma == nullptr: dst = src); pitch != 0: src is a vector of a chunk-interleaved basis
+void launch_unscale(hipStream_t st, const double *src, const double *sigma, int k, double *dst, int64_t n,
+                    int64_t pitch = 0);
 
 // ---- implicit-Euler assembly ------------------------------------------------
 struct IeGeom {

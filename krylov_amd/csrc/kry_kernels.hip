@@ -106,7 +106,8 @@ __global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict_
                                                         double *__restrict__ dst,
                                                         const double *__restrict__ part, int np,
                                                         int64_t n, double *__restrict__ out,
-                                                        const int *__restrict__ stop) {
+                                                        const int *__restrict__ stop, int64_t pitch,
+                                                        double *__restrict__ dst2) {
   if (stopped(stop)) return;
   __shared__ double s[kBlock / 64];
   const double nrm = sqrt(sum_parts(part, np, s));
@@ -130,11 +131,15 @@ __global__ __launch_bounds__(kBlock) void k_scale_from(const double *__restrict_
         d2 r;
         r.x = v[u].x / nrm;
         r.y = v[u].y / nrm;
-        st_nt(r, &o2[i]);
+        st_nt(r, &o2[il2(i, pitch)]);
+        if (dst2 != nullptr) st_nt(r, reinterpret_cast<d2 *>(dst2) + i);
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1] / nrm;
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    dst[il1(n - 1, pitch)] = src[n - 1] / nrm;
+    if (dst2 != nullptr) dst2[n - 1] = src[n - 1] / nrm;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
                                                        double *__restrict__ part_out,
                                                        double *__restrict__ hout, int hstride,
                                                        int64_t n, double *__restrict__ G, int gld, int gp,
-                                                       const int *__restrict__ stop) {
+                                                       const int *__restrict__ stop, int64_t pitch) {
   if (stopped(stop)) return;
   constexpr int NQI = nred(KP);
   constexpr int NQO = NORM ? 1 : nred(KC);
@@ -214,10 +219,11 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
       const int64_t i = base + u * kBlock + threadIdx.x;
       if (i < n2) {
         wv[u] = ld_nt(&w2[i]);
+        const int64_t iv = il2(i, pitch);
 #pragma unroll
-        for (int k = 0; k < KP; k++) pv[k][u] = ld_nt(reinterpret_cast<const d2 *>(pbase + (int64_t)k * ld) + i);
+        for (int k = 0; k < KP; k++) pv[k][u] = ld_nt(reinterpret_cast<const d2 *>(pbase + (int64_t)k * ld) + iv);
 #pragma unroll
-        for (int k = 0; k < KC; k++) cv[k][u] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)k * ld) + i);
+        for (int k = 0; k < KC; k++) cv[k][u] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)k * ld) + iv);
       }
     }
 #pragma unroll
@@ -246,19 +252,19 @@ __global__ __launch_bounds__(kBlock) void k_mgs_block(double *__restrict__ w,
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail element
-    const int64_t e = n - 1;
+    const int64_t e = n - 1, ev = il1(e, pitch);
     double r = w[e];
 #pragma unroll
-    for (int k = 0; k < KP; k++) r = r - h[k] * pbase[(int64_t)k * ld + e];
+    for (int k = 0; k < KP; k++) r = r - h[k] * pbase[(int64_t)k * ld + ev];
     w[e] = r;
     if (NORM) {
       acc[0] = fma(r, r, acc[0]);
     } else {
 #pragma unroll
       for (int a = 0; a < KC; a++) {
-        acc[a] = fma(r, cbase[(int64_t)a * ld + e], acc[a]);
+        acc[a] = fma(r, cbase[(int64_t)a * ld + ev], acc[a]);
         if (a < KC - 1)
-          acc[KC + a] = fma(cbase[(int64_t)a * ld + e], cbase[(int64_t)(KC - 1) * ld + e], acc[KC + a]);
+          acc[KC + a] = fma(cbase[(int64_t)a * ld + ev], cbase[(int64_t)(KC - 1) * ld + ev], acc[KC + a]);
       }
     }
   }
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V
                                                      const double *__restrict__ y, int m,
                                                      double *__restrict__ x, int64_t n,
                                                      const int *__restrict__ count, int accumulate,
-                                                     const double *__restrict__ sigma) {
+                                                     const double *__restrict__ sigma, int64_t pitch) {
   __shared__ double ys[kMaxM];
   if (count != nullptr) {
     const int c = *count;
@@ -287,16 +293,17 @@ __global__ __launch_bounds__(kBlock) void k_combine(const double *__restrict__ V
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     d2 acc = {0.0, 0.0};
     if (accumulate) acc = x2[i];
+    const int64_t iv = il2(i, pitch);
 #pragma unroll 8
     for (int k = 0; k < m; k++) {
-      const d2 v = ld_nt(reinterpret_cast<const d2 *>(V + (int64_t)k * ld) + i);
+      const d2 v = ld_nt(reinterpret_cast<const d2 *>(V + (int64_t)k * ld) + iv);
       acc = acc + ys[k] * v;
     }
     st_nt(acc, &x2[i]);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double acc = accumulate ? x[n - 1] : 0.0;
-    for (int k = 0; k < m; k++) acc = acc + ys[k] * V[(int64_t)k * ld + n - 1];
+    for (int k = 0; k < m; k++) acc = acc + ys[k] * V[(int64_t)k * ld + il1(n - 1, pitch)];
     x[n - 1] = acc;
   }
 }
@@ -439,10 +446,11 @@ __global__ __launch_bounds__(64) void k_ext_solve(const double *__restrict__ R, 
 // ---------------------------------------------------------------------------
 template <int KC>
 __device__ __forceinline__ void accum_scalar(double r, const double *__restrict__ cbase, int64_t ld,
-                                             int64_t k, double (&acc)[KC > 0 ? nred(KC) : 1]) {
+                                             int64_t k, double (&acc)[KC > 0 ? nred(KC) : 1], int64_t pitch) {
   double c[KC > 0 ? KC : 1];
+  const int64_t kv = il1(k, pitch);
 #pragma unroll
-  for (int a = 0; a < KC; a++) c[a] = cbase[(int64_t)a * ld + k];
+  for (int a = 0; a < KC; a++) c[a] = cbase[(int64_t)a * ld + kv];
   if constexpr (KC > 0) {
 #pragma unroll
     for (int a = 0; a < KC; a++) {
@@ -459,7 +467,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
                                                           const double *__restrict__ x,
                                                           double *__restrict__ y,
                                                           const double *__restrict__ cbase, int64_t ld,
-                                                          double *__restrict__ part, const int *__restrict__ stop) {
+                                                          double *__restrict__ part, const int *__restrict__ stop,
+                                                          int64_t pitch) {
   if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
     r = r + b.n[k] * xn;
     r = r + b.e[k] * xe;
     y[k] = r;
-    if (KC > 0) accum_scalar<KC>(r, cbase, ld, k, acc);
+    if (KC > 0) accum_scalar<KC>(r, cbase, ld, k, acc, pitch);
   }
   if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
 }
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
                                                              double *__restrict__ y,
                                                              const double *__restrict__ cbase, int64_t ld,
                                                              double *__restrict__ part, const int *__restrict__ stop,
-                                                             BandGen gen = BandGen()) {
+                                                             BandGen gen, int64_t pitch) {
   if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
         }
         d2 cv[KC > 0 ? KC : 1];
 #pragma unroll
-        for (int a = 0; a < KC; a++) cv[a] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)a * ld) + i);
+        for (int a = 0; a < KC; a++) cv[a] = ld_nt(reinterpret_cast<const d2 *>(cbase + (int64_t)a * ld) + il2(i, pitch));
         double r0 = 0.0, r1 = 0.0;
         r0 = r0 + cw.x * xw.x;
         r1 = r1 + cw.y * xw.y;
@@ -629,7 +638,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__
                                                       const double *__restrict__ x,
                                                       double *__restrict__ y,
                                                       const double *__restrict__ cbase, int64_t ld,
-                                                      double *__restrict__ part, const int *__restrict__ stop) {
+                                                      double *__restrict__ part, const int *__restrict__ stop,
+                                                      int64_t pitch) {
   if (stopped(stop)) return;
   constexpr int NQ = KC > 0 ? nred(KC) : 1;
   __shared__ double red[NQ * (kBlock / 64)];
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_csr(const int64_t *__restrict__
     }
     if (r < n) {
       y[r] = sum;
-      if (KC > 0) accum_scalar<KC>(sum, cbase, ld, r, acc);
+      if (KC > 0) accum_scalar<KC>(sum, cbase, ld, r, acc, pitch);
     }
   }
   if (KC > 0) reduce_store_multi<NQ>(acc, red, part);
@@ -1083,6 +1093,23 @@ __device__ __forceinline__ void tdp2_flush(const TdpTile<LPW> &t, double *a, int
   }
 }
 
+// Normalisation on the way in: a fetched chunk of the un-normalised vector is divided by its norm (true
+// division, as normalize() in include/matrix.hpp:54-60 and k_scale_from), stored to the basis slot it belongs
+// to and handed on to the solve.
+template <int LPW>
+__device__ __forceinline__ void tdp2_scale_store(d2 (&r)[LPW / 2], double nrm, double *v, int64_t pitch, int64_t line0,
+                                                 int nl, int64_t L, int64_t col0, int lane) {
+  const int64_t e0 = line0 * L + col0 + 2 * (lane & 31);
+  const int h = lane >> 5;
+#pragma unroll
+  for (int p = 0; p < LPW / 2; p++) {
+    const int line = 2 * p + h < nl ? 2 * p + h : nl - 1;
+    r[p].x = r[p].x / nrm;
+    r[p].y = r[p].y / nrm;
+    st_nt(r[p], reinterpret_cast<d2 *>(v + il1(e0 + line * L, pitch)));
+  }
+}
+
 // 8-byte counterparts for the incomplete chunk at the end of a line, with the same treatment
 // of missing lines (their lanes must keep walking copies of the last line, or their stores
 // in the back substitution would put other values at that line's addresses)
@@ -1124,12 +1151,17 @@ __device__ __forceinline__ double tdp_walk_backward_small(TdpTile<LPW> &ts, cons
   return prev;
 }
 
-template <int LPW, int DF = kTdpAheadF, int DB = kTdpAheadB>
+// SC: sol is the un-normalised work vector of an Arnoldi step and sc.part the partial sums of its squares.  The
+// solve takes sol / nrm, nrm = sqrt(sum of sc.part) -- the expression tree of sum_parts for 256 threads, evaluated
+// by the workgroup's one wavefront, so the bits k_scale_from would obtain -- and stores that vector to sc.vout
+// (sc.pitch: as a vector of a chunk-interleaved basis) and nrm to *sc.nout: the normalisation at the end of
+// gram_schmidt (include/solver.hpp:209) and M^-1 v (:290-328) in one pass over the vector.  Needs L >= 8 * 64.
+template <int LPW, bool SC = false, int DF = kTdpAheadF, int DB = kTdpAheadB>
 __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__ lo,
                                                        const double *__restrict__ dd,
                                                        const double *__restrict__ ud, const double *sol,
                                                        double *out, int64_t nlines, int64_t L,
-                                                       const int *__restrict__ stop) {
+                                                       const int *__restrict__ stop, TdpScale sc) {
   if (stopped(stop)) return;
   static_assert(LPW % 2 == 0, "two lines per request");
   constexpr int H = LPW / 2, C = kTdpC;
@@ -1140,8 +1172,23 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
   const int64_t nfull = L / C;  // chunks whose 64 columns all exist
   const int tail = (int)(L - nfull * C);  // columns of the incomplete chunk behind them
   if (nfull < 8) {
-    tdp_apply_lines<LPW>(ts, ta, td, lo, dd, ud, sol, out, line0, nl, L, lane);
+    if (!SC) tdp_apply_lines<LPW>(ts, ta, td, lo, dd, ud, sol, out, line0, nl, L, lane);
     return;
+  }
+  double nrm = 1.0;
+  if (SC) {
+    double t[kBlock / 64];
+#pragma unroll
+    for (int wv = 0; wv < kBlock / 64; wv++) {
+      double a = 0.0;
+      for (int i = wv * 64 + lane; i < sc.np; i += kBlock) a += sc.part[i];
+      t[wv] = wave_sum(a);
+    }
+    double tot = t[0];
+#pragma unroll
+    for (int wv = 1; wv < kBlock / 64; wv++) tot += t[wv];
+    nrm = sqrt(__shfl(tot, 0, 64));
+    if (blockIdx.x == 0 && lane == 0 && sc.nout != nullptr) *sc.nout = nrm;
   }
   const bool walker = lane < LPW;
   double prev = 0.0;
@@ -1161,6 +1208,7 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
       for (int p = 0; p < H; p++) ra[0][p].x = 0.0;
     }
     // chunk 0: nothing to flush yet
+    if (SC) tdp2_scale_store<LPW>(rs[0], nrm, sc.vout, sc.pitch, line0, nl, L, 0, lane);
     tdp2_park<LPW>(ts[0], rs[0], lane);
     tdp2_park<LPW>(ta, ra[0], lane);
     tdp2_park<LPW>(td, rd[0], lane);
@@ -1178,6 +1226,7 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
         const int64_t cc = c + k;
         const int64_t cf = (cc + D < nfull ? cc + D : nfull - 1) * C;  // past the end: a chunk nobody uses
         TdpTile<LPW> &cur = ts[cc & 1];
+        if (SC) tdp2_scale_store<LPW>(rs[set], nrm, sc.vout, sc.pitch, line0, nl, L, cc * C, lane);
         tdp2_park<LPW>(cur, rs[set], lane);
         tdp2_park<LPW>(ta, ra[set], lane);
         tdp2_park<LPW>(td, rd[set], lane);
@@ -1197,6 +1246,7 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
       const int64_t cc = c + k;
       if (cc < nfull) {
         TdpTile<LPW> &cur = ts[cc & 1];
+        if (SC) tdp2_scale_store<LPW>(rs[set], nrm, sc.vout, sc.pitch, line0, nl, L, cc * C, lane);
         tdp2_park<LPW>(cur, rs[set], lane);
         tdp2_park<LPW>(ta, ra[set], lane);
         tdp2_park<LPW>(td, rd[set], lane);
@@ -1226,6 +1276,13 @@ __global__ __launch_bounds__(kTdpC) void k_tdp_apply2(const double *__restrict__
       tdp_fetch_dup<LPW>(r8s, sol, line0, nl, L, col, 0.0);
       tdp_fetch_dup<LPW>(r8a, lo, line0, nl, L, col, 0.0);
       tdp_fetch_dup<LPW>(r8d, dd, line0, nl, L, col, 1.0);
+      if (SC && col < L) {
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+          r8s[i] = r8s[i] / nrm;
+          sc.vout[il1((line0 + (i < nl ? i : nl - 1)) * L + col, sc.pitch)] = r8s[i];
+        }
+      }
       tp ^= 1;
       tdp_park<LPW>(ts[tp], r8s, lane);
       tdp_park<LPW>(ta, r8a, lane);
@@ -2067,15 +2124,15 @@ void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, 
 }
 
 void launch_scale_from(hipStream_t st, const double *src, double *dst, const double *part,
-                       int nparts, int64_t n, double *out) {
+                       int nparts, int64_t n, double *out, int64_t pitch, double *dst2) {
   const int g = stream_grid(n >> 1, 4, 1024);
-  hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out, t_stop);
+  hipLaunchKernelGGL(k_scale_from, dim3(g), dim3(kBlock), 0, st, src, dst, part, nparts, n, out, t_stop, pitch, dst2);
 }
 
 template <int KC, bool HALO>
 static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                                   double *y, const double *cbase, int64_t ld, double *part, int *nparts,
-                                  const BandGen *gen) {
+                                  const BandGen *gen, int64_t pitch) {
   const bool vec = (cols % 2 == 0) && (n % 2 == 0);
   // 13+ streams with cached x rows: two elements per lane, one workgroup per CU (measured optimum)
   constexpr int U = 2;
@@ -2087,45 +2144,46 @@ static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int
   if (nparts) *nparts = g;
   if (vec && gen != nullptr)
     hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U, true>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part,
-                       t_stop, *gen);
+                       t_stop, *gen, pitch);
   else if (vec)
     hipLaunchKernelGGL((k_spmv_stencil_v2<KC, HALO, U, false>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part,
-                       t_stop, BandGen());
+                       t_stop, BandGen(), pitch);
   else
-    hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop);
+    hipLaunchKernelGGL((k_spmv_stencil<KC, HALO>), dim3(g), dim3(kBlock), 0, st, b, n, cols, x, y, cbase, ld, part, t_stop,
+                       pitch);
 }
 
 // kc -> template argument (0..kMgsBlock)
 template <bool HALO, int KC = kMgsBlock>
 struct SpmvStencilKc {
   static void go(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x, double *y, int kc,
-                 const double *cbase, int64_t ld, double *part, int *nparts, const BandGen *gen) {
+                 const double *cbase, int64_t ld, double *part, int *nparts, const BandGen *gen, int64_t pitch) {
     if (kc == KC)
-      launch_spmv_stencil_t<KC, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts, gen);
+      launch_spmv_stencil_t<KC, HALO>(st, b, n, cols, x, y, cbase, ld, part, nparts, gen, pitch);
     else
-      SpmvStencilKc<HALO, KC - 1>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
+      SpmvStencilKc<HALO, KC - 1>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen, pitch);
   }
 };
 template <bool HALO>
 struct SpmvStencilKc<HALO, -1> {
   static void go(hipStream_t, const Bands &, int64_t, int, const double *, double *, int, const double *, int64_t,
-                 double *, int *, const BandGen *) {}
+                 double *, int *, const BandGen *, int64_t) {}
 };
 
 template <bool HALO>
 static void launch_spmv_stencil_h(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                                   double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts,
-                                  const BandGen *gen) {
-  SpmvStencilKc<HALO>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
+                                  const BandGen *gen, int64_t pitch) {
+  SpmvStencilKc<HALO>::go(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen, pitch);
 }
 
 void launch_spmv_stencil(hipStream_t st, const Bands &b, int64_t n, int cols, const double *x,
                          double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts,
-                         bool x_has_halo, const BandGen *gen) {
+                         bool x_has_halo, const BandGen *gen, int64_t pitch) {
   if (x_has_halo)
-    launch_spmv_stencil_h<true>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
+    launch_spmv_stencil_h<true>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen, pitch);
   else
-    launch_spmv_stencil_h<false>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen);
+    launch_spmv_stencil_h<false>(st, b, n, cols, x, y, kc, cbase, ld, part, nparts, gen, pitch);
 }
 
 void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, double *tot) {
@@ -2135,32 +2193,34 @@ void launch_reduce_parts(hipStream_t st, const double *part, int nq, int np, dou
 template <int KC>
 static void launch_spmv_csr_t(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
                               int64_t n, const double *x, double *y, const double *cbase, int64_t ld,
-                              double *part, int *nparts) {
+                              double *part, int *nparts, int64_t pitch) {
   const int g = grid_for(n);
   if (nparts) *nparts = g;
-  hipLaunchKernelGGL((k_spmv_csr<KC>), dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, cbase, ld, part, t_stop);
+  hipLaunchKernelGGL((k_spmv_csr<KC>), dim3(g), dim3(kBlock), 0, st, rowptr, col, val, n, x, y, cbase, ld, part, t_stop,
+                     pitch);
 }
 
 template <int KC = kMgsBlock>
 struct SpmvCsrKc {
   static void go(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val, int64_t n,
-                 const double *x, double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts) {
+                 const double *x, double *y, int kc, const double *cbase, int64_t ld, double *part, int *nparts,
+                 int64_t pitch) {
     if (kc == KC)
-      launch_spmv_csr_t<KC>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts);
+      launch_spmv_csr_t<KC>(st, rowptr, col, val, n, x, y, cbase, ld, part, nparts, pitch);
     else
-      SpmvCsrKc<KC - 1>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts);
+      SpmvCsrKc<KC - 1>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts, pitch);
   }
 };
 template <>
 struct SpmvCsrKc<-1> {
   static void go(hipStream_t, const int64_t *, const int32_t *, const double *, int64_t, const double *, double *, int,
-                 const double *, int64_t, double *, int *) {}
+                 const double *, int64_t, double *, int *, int64_t) {}
 };
 
 void launch_spmv_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col, const double *val,
                      int64_t n, const double *x, double *y, int kc, const double *cbase, int64_t ld,
-                     double *part, int *nparts) {
-  SpmvCsrKc<>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts);
+                     double *part, int *nparts, int64_t pitch) {
+  SpmvCsrKc<>::go(st, rowptr, col, val, n, x, y, kc, cbase, ld, part, nparts, pitch);
 }
 
 struct MgsArgs {
@@ -2176,6 +2236,7 @@ struct MgsArgs {
   int64_t n;
   double *G;
   int gld, gp;
+  int64_t pitch;
 };
 
 template <int KP, int KC, bool NORM>
@@ -2185,7 +2246,7 @@ static void launch_mgs_block_t(hipStream_t st, const MgsArgs &a) {
   const int g = sweep_grid(a.n >> 1, streams, U);
   *a.np_out = g;
   hipLaunchKernelGGL((k_mgs_block<KP, KC, NORM, U>), dim3(g), dim3(kBlock), 0, st, a.w, a.pbase, a.cbase, a.ld,
-                     a.part_in, a.np_in, a.part_out, a.hout, a.hstride, a.n, a.G, a.gld, a.gp, t_stop);
+                     a.part_in, a.np_in, a.part_out, a.hout, a.hstride, a.n, a.G, a.gld, a.gp, t_stop, a.pitch);
 }
 
 // (kp, kc) -> template arguments.  Groups are aligned, so a sweep either joins two
@@ -2226,8 +2287,8 @@ bool mgs_block_supported(int k) { return k == 1 || k == 2 || k == 3 || k == 4 ||
 void launch_mgs_block(hipStream_t st, int kp, int kc, double *w, const double *pbase,
                       const double *cbase, int64_t ld, const double *part_in, int np_in,
                       double *part_out, int *np_out, double *hout, int hstride, int64_t n, double *G,
-                      int gld, int gp) {
-  const MgsArgs a{w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n, G, gld, gp};
+                      int gld, int gp, int64_t pitch) {
+  const MgsArgs a{w, pbase, cbase, ld, part_in, np_in, part_out, np_out, hout, hstride, n, G, gld, gp, pitch};
   if (kc == 0) {
     MgsClosing<>::go(st, kp, a);
     return;
@@ -2258,9 +2319,10 @@ void launch_small_solve(hipStream_t st, const double *H, const double *beta, int
 }
 
 void launch_combine(hipStream_t st, const double *V, int64_t ld, const double *y, int m, double *x,
-                    int64_t n, const int *count, bool accumulate, const double *sigma) {
+                    int64_t n, const int *count, bool accumulate, const double *sigma, int64_t pitch) {
   const int g = grid_for((n + 1) / 2);
-  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n, count, accumulate ? 1 : 0, sigma);
+  hipLaunchKernelGGL(k_combine, dim3(g), dim3(kBlock), 0, st, V, ld, y, m, x, n, count, accumulate ? 1 : 0, sigma,
+                     pitch);
 }
 
 void launch_add(hipStream_t st, double *x, const double *w, int64_t n) {
@@ -2338,7 +2400,8 @@ void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const 
   if (pairs && tdp_lines_per_wave(nlines) == 16 && L % 2 == 0 && aligned16(lo) && aligned16(dd) && aligned16(ud) &&
       aligned16(sol) && aligned16(out)) {
     const int g = (int)((nlines + 15) / 16);
-    hipLaunchKernelGGL(k_tdp_apply2<16>, dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L, t_stop);
+    hipLaunchKernelGGL((k_tdp_apply2<16, false>), dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L, t_stop,
+                       TdpScale());
     return;
   }
   switch (tdp_lines_per_wave(nlines)) {
@@ -2348,6 +2411,19 @@ void launch_tdp_apply(hipStream_t st, const double *lo, const double *dd, const 
     case 2: launch_tdp_apply_t<2>(st, lo, dd, ud, sol, out, nlines, L); break;
     default: launch_tdp_apply_t<1>(st, lo, dd, ud, sol, out, nlines, L); break;
   }
+}
+
+bool tdp_scaled_supported(const double *lo, const double *dd, const double *ud, const double *sol, const double *out,
+                          const double *vout, int64_t nlines, int64_t L) {
+  const auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return tdp_lines_per_wave(nlines) == 16 && L % 2 == 0 && L >= 8 * kTdpC && aligned16(lo) && aligned16(dd) &&
+         aligned16(ud) && aligned16(sol) && aligned16(out) && aligned16(vout);
+}
+
+void launch_tdp_apply_scaled(hipStream_t st, const double *lo, const double *dd, const double *ud, const double *sol,
+                             double *out, int64_t nlines, int64_t L, const TdpScale &sc) {
+  const int g = (int)((nlines + 15) / 16);
+  hipLaunchKernelGGL((k_tdp_apply2<16, true>), dim3(g), dim3(kTdpC), 0, st, lo, dd, ud, sol, out, nlines, L, t_stop, sc);
 }
 
 void launch_tdp_extract_csr(hipStream_t st, const int64_t *rowptr, const int32_t *col,

@@ -210,6 +210,10 @@ class GMRESSolver:
         """Whether the basis of the last solve was stored strip by strip."""
         return bool(capi.lib().kry_gmres_basis_strip_major(self.h))
 
+    def basis_chunk_interleaved(self):
+        """Whether the basis of the last solve was stored chunk-interleaved (chain-only solves on one rank)."""
+        return bool(capi.lib().kry_gmres_basis_chunk_interleaved(self.h))
+
     def set_norm_from_sums(self, on):
         """H(m, m-1) from the last sweep's sums (default for a step object's solver) or from the closing pass."""
         check(capi.lib().kry_gmres_set_norm_from_sums(self.h, int(bool(on))))
