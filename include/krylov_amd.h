@@ -112,6 +112,18 @@ int kry_ctx_nranks(const kry_ctx *ctx);
  * the stream, returns the totals since the previous call and resets them. */
 int kry_ctx_set_kernel_timing(kry_ctx *ctx, int on);
 int kry_ctx_get_kernel_times(kry_ctx *ctx, double ms[], int launches[]);
+/* Self-test of an arithmetic shortcut, without a counterpart in the reference.  Kernels that evaluate the
+ * off-diagonal entries of the implicit-Euler operator on the fly (SecondOrderCentered::Dx_m1 / Dx_p1 / Dy_m1 /
+ * Dy_p1, include/space_disc.hpp:83-113: four numerators over the mesh widths dx, dy per cell) replace the
+ * division instruction sequence by five multiply-adds with a correctly rounded reciprocal, inside a guarded
+ * range in which that yields the correctly rounded quotient, and fall back to the division outside it.  This
+ * entry point runs that code for `count` groups of four pseudo-random numerators and compares every quotient
+ * with the device's division, bit for bit.  mode 0: numerators within 2^+-40 of 1; 1: arbitrary bit patterns
+ * (zeros, subnormals, infinities, NaNs); 2: quotients around the limits of the guarded range; 3: quotients next
+ * to powers of two and to midpoints between neighbouring numbers.  *mismatches: quotients that differ (must be
+ * 0); *fast_groups (may be NULL): groups served by the shortcut. */
+int kry_selftest_shared_division(kry_ctx *ctx, double dx, double dy, uint64_t seed, int64_t count, int mode,
+                                 int64_t *mismatches, int64_t *fast_groups);
 
 /* ---- operators: stand-ins for the dense `matrix` handed to Solver::solve ----
  * reference: dot(vector&, const matrix&, const vector&), include/matrix.hpp:23-33 */

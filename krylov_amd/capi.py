@@ -70,6 +70,8 @@ SIGNATURES = {
     "kry_gmres_get_one_sweep": (C.c_int, [_vp]),
     "kry_gmres_basis_strip_major": (C.c_int, [_vp]),
     "kry_gmres_basis_chunk_interleaved": (C.c_int, [_vp]),
+    "kry_selftest_shared_division": (C.c_int, [_vp, C.c_double, C.c_double, C.c_uint64, C.c_int64, C.c_int,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "kry_gmres_set_norm_from_sums": (C.c_int, [_vp, C.c_int]),
     "kry_gmres_get_norm_from_sums": (C.c_int, [_vp]),
     "kry_gmres_last_norm_from_sums": (C.c_int, [_vp, C.POINTER(C.c_int)]),

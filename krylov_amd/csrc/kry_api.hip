@@ -689,6 +689,33 @@ static int launch_ok(const char *what) {
   return KRY_OK;
 }
 
+extern "C" {
+
+int kry_selftest_shared_division(kry_ctx *ctx, double dx, double dy, uint64_t seed, int64_t count, int mode,
+                                 int64_t *mismatches, int64_t *fast_groups) {
+  if (!ctx || !mismatches) return fail(KRY_ERR_INVALID, "NULL argument");
+  if (count < 0 || mode < 0 || mode > 3) return fail(KRY_ERR_INVALID, "count must not be negative, mode in 0..3");
+  HIPCHK(hipSetDevice(ctx->device));
+  unsigned long long *dev = nullptr, h[2] = {0, 0};
+  HIPCHK(hipMalloc((void **)&dev, sizeof(h)));
+  int st = KRY_OK;
+  if (hipMemsetAsync(dev, 0, sizeof(h), ctx->stream) != hipSuccess) st = fail(KRY_ERR_HIP, "hipMemsetAsync failed");
+  if (st == KRY_OK) {
+    launch_selftest_division(ctx->stream, dx, dy, seed, count, mode, dev);
+    st = launch_ok("kry_selftest_shared_division");
+  }
+  if (st == KRY_OK && hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    st = fail(KRY_ERR_HIP, "hipMemcpyAsync failed");
+  if (st == KRY_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(KRY_ERR_HIP, "sync failed");
+  (void)hipFree(dev);
+  if (st != KRY_OK) return st;
+  *mismatches = (int64_t)h[0];
+  if (fast_groups) *fast_groups = (int64_t)h[1];
+  return KRY_OK;
+}
+
+}  // extern "C"
+
 // ---------------------------------------------------------------------------
 // Operators
 // ---------------------------------------------------------------------------
@@ -2103,6 +2130,10 @@ int kry_ie_init_offdiag(kry_ie *ie) {
     gen.ky = ie->g.diffusion * ie->g.inv_rp / ie->g.dy;
     gen.dx = ie->g.dx;
     gen.dy = ie->g.dy;
+    gen.rdx = 1.0 / gen.dx;
+    gen.rdy = 1.0 / gen.dy;
+    static const bool fast_div = !(getenv("KRY_GEN_DIVIDE") && atoi(getenv("KRY_GEN_DIVIDE")) != 0);  // experimentation knob
+    gen.div_ok = fast_div && shared_divisor_in_range(gen.dx) && shared_divisor_in_range(gen.dy);
     gen.row0 = ie->g.row0;
     gen.cx = ie->g.cx;
     gen.cy = ie->g.cy;

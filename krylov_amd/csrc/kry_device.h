@@ -54,6 +54,75 @@ __device__ __forceinline__ int64_t il2(int64_t i2, int64_t pitch) {
   return pitch ? (i2 / (kChunk / 2)) * (pitch / 2) + (i2 % (kChunk / 2)) : i2;
 }
 
+// ---------------------------------------------------------------------------
+// a / d, correctly rounded, for a divisor that many divisions share.
+//
+// With y = RN(1 / d) (one true division), q0 = RN(a y) is within two units in the last place of a / d; one
+// correction q1 = RN(q0 + (a - d q0) y), the residual formed by a fused multiply-add, is within half a unit plus
+// a relative 2^-104, i.e. it is one of the two neighbours of a / d; and for such a q1, with the residual
+// r1 = a - d q1 exact, RN(q1 + r1 y) IS RN(a / d) (Markstein's theorem on division by correction with a
+// correctly rounded reciprocal).  Five multiply-adds at full rate instead of the division sequence with its
+// quarter-rate reciprocal.  The proof needs every intermediate to be a normal number and r1 to be exact, which
+// holds when 2^-100 <= |d| < 2^101 and 2^-800 <= |q| < 2^801 (then the quantum of d q1, 2^-104 |d q|, is far above
+// the smallest subnormal); callers test both (shared_divisor().ok for d, div_shared_in_range for the quotient;
+// zero, infinite and NaN quotients fail the test) and take the true division for a whole wavefront when any
+// lane fails, so every result has the bits of a / d.
+// ---------------------------------------------------------------------------
+struct SharedDivisor {
+  double d, y;
+  bool ok;
+};
+__device__ __forceinline__ uint32_t exponent_field(double x) { return ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu; }
+// y: RN(1 / d), from one true division (on the host for divisors that come with the launch, which keeps d and y
+// in scalar registers); ok: shared_divisor_in_range(d)
+__device__ __forceinline__ SharedDivisor shared_divisor(double d, double y, bool ok) {
+  SharedDivisor s;
+  s.d = d;
+  s.y = y;
+  s.ok = ok;
+  return s;
+}
+__device__ __forceinline__ double div_shared_fast(double a, const SharedDivisor &s) {
+  double q = a * s.y;
+  double r = fma(-s.d, q, a);
+  q = fma(r, s.y, q);
+  r = fma(-s.d, q, a);
+  return fma(r, s.y, q);
+}
+__device__ __forceinline__ bool div_shared_in_range(double q) { return exponent_field(q) - 223u <= 1600u; }
+
+// (the value itself behind an empty asm statement: a select on it stays a select instead of becoming a branch
+// around the arithmetic that produced it)
+__device__ __forceinline__ double div_opaque(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// The four quotients in a row's band entries (numerators over the two mesh widths, which the whole sweep
+// shares) by div_shared_fast; a wavefront in which any quotient leaves the range in which that is proven exact
+// takes the true divisions instead.  Either way the bits of n / d, as k_offdiag forms them.
+__device__ __forceinline__ bool band_quotients(double n0, double n1, double n2, double n3, const SharedDivisor &dx,
+                                               const SharedDivisor &dy, double &iw, double &is, double &in, double &ie) {
+  iw = div_shared_fast(n0, dx);
+  is = div_shared_fast(n1, dy);
+  in = div_shared_fast(n2, dy);
+  ie = div_shared_fast(n3, dx);
+  const bool ok = dx.ok && dy.ok && div_shared_in_range(iw) && div_shared_in_range(is) && div_shared_in_range(in) &&
+                  div_shared_in_range(ie);
+  const bool fast = __all(ok);
+  if (!fast) {
+    iw = n0 / dx.d;
+    is = n1 / dy.d;
+    in = n2 / dy.d;
+    ie = n3 / dx.d;
+  }
+  iw = div_opaque(iw);
+  is = div_opaque(is);
+  in = div_opaque(in);
+  ie = div_opaque(ie);
+  return fast;  // (for the self-test)
+}
+
 __device__ __forceinline__ d2 ld_nt(const d2 *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_nt(d2 v, d2 *p) { __builtin_nontemporal_store(v, p); }
 

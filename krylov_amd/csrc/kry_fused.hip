@@ -351,6 +351,8 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
   }
 
   const double gdiag = GEN ? gdiag_of(gen) : 0.0;
+  // the mesh widths with their reciprocals, for the quotients in the band entries (see div_shared_fast)
+  const SharedDivisor sdx = shared_divisor(gen.dx, gen.rdx, gen.div_ok != 0), sdy = shared_divisor(gen.dy, gen.rdy, gen.div_ok != 0);
   // The values requested for a round.  S sets take turns (the loop below is unrolled S
   // times): a value requested into the registers a later round reads needs no copy at
   // the end of the round, which would have to wait for it.  The round that works on row
@@ -427,10 +429,9 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
       const int ip = gen.row0 + rr;
       const bool xin = ip >= 1 && ip <= gen.cx;
       // SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1, include/space_disc.hpp:83-113, as k_offdiag forms them
-      const double iw = opaque((-gum / 2.0 - gen.kx) / gen.dx);
-      const double is = opaque((-o.b[1] / 2.0 - gen.ky) / gen.dy);
-      const double in = opaque((o.b[3] / 2.0 - gen.ky) / gen.dy);
-      const double ie = opaque((gup / 2.0 - gen.kx) / gen.dx);
+      double iw, is, in, ie;
+      band_quotients(-gum / 2.0 - gen.kx, -o.b[1] / 2.0 - gen.ky, o.b[3] / 2.0 - gen.ky, gup / 2.0 - gen.kx, sdx, sdy, iw, is,
+                     in, ie);
       const bool inner = xin && yin;
       // ghost rows as k_assemble leaves them (include/time_disc.hpp:304-337)
       bc[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_fused(FusedGeom geo, Bands b
 // vectors.  Per lane that is half the registers, so two wavefronts fit a SIMD where the
 // kernel above runs with one, and the arithmetic of one overlaps the waiting of the other.
 constexpr int kSplitBlock = 2 * kBlock;
-constexpr int kUniformHalfUpto = 35;
+constexpr int kUniformHalfUpto = 34;
 constexpr int kSplitFrom = 18;  // first step served by it (measured per instantiation on an 8192 x 8192 grid)
 // rows stored together: as many as the LDS left beside the parked vectors holds
 constexpr int split_store_rows(int nv) { return nv <= 40 ? 32 : 16; }
@@ -678,6 +679,8 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
   };
   Req qa, qb;
   const double gdiag = GEN ? gdiag_of(gen) : 0.0;
+  // the mesh widths with their reciprocals, for the quotients in the band entries (see div_shared_fast)
+  const SharedDivisor sdx = shared_divisor(gen.dx, gen.rdx, gen.div_ok != 0), sdy = shared_divisor(gen.dy, gen.rdy, gen.div_ok != 0);
   double gu0 = 0.0, gu1 = 0.0;
   const bool yin = GEN && c >= 1 && c <= gen.cy;
   auto issue_op = [&](Req &n, int r) __attribute__((always_inline)) {
@@ -777,10 +780,8 @@ __global__ __launch_bounds__(kSplitBlock) void k_arnoldi_split(FusedGeom geo, Ba
                          double *out) __attribute__((always_inline)) {
     const int ip = gen.row0 + row;
     const bool xin = ip >= 1 && ip <= gen.cx;
-    const double iw = opaque((-gum / 2.0 - gen.kx) / gen.dx);
-    const double is = opaque((-vm / 2.0 - gen.ky) / gen.dy);
-    const double in = opaque((vp / 2.0 - gen.ky) / gen.dy);
-    const double ie = opaque((gup / 2.0 - gen.kx) / gen.dx);
+    double iw, is, in, ie;
+    band_quotients(-gum / 2.0 - gen.kx, -vm / 2.0 - gen.ky, vp / 2.0 - gen.ky, gup / 2.0 - gen.kx, sdx, sdy, iw, is, in, ie);
     const bool inner = xin && yin;
     out[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
     out[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);

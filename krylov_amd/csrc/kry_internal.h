@@ -34,10 +34,22 @@ struct Bands {
 // and all interior cells share one diagonal value.  A kernel that holds a recipe
 // evaluates those entries (same operations as k_offdiag, hence the same bits) instead
 // of reading them; the entries of ghost rows and columns follow from their position.
+// 2^-100 <= |d| < 2^101: the divisors for which the kernels replace divisions by corrections with a correctly
+// rounded reciprocal (div_shared_fast in kry_device.h)
+__host__ __device__ inline bool shared_divisor_in_range(double d) {
+  uint64_t bits;
+  __builtin_memcpy(&bits, &d, sizeof bits);
+  return (uint32_t)((bits >> 52) & 0x7ffu) - 923u <= 200u;
+}
+
 struct BandGen {
   const double *u = nullptr, *v = nullptr;  // velocity snapshots, laid out like the fields (halo row in front and behind)
   const double *cdiag = nullptr;            // the diagonal entry of one interior cell (any entry when the rank owns none)
   double kx = 0.0, ky = 0.0, dx = 1.0, dy = 1.0;  // kx = diffusion / (Re Pr) / dx, ky likewise, as k_offdiag forms them
+  // 1 / dx and 1 / dy, correctly rounded (one IEEE division each on the host), and whether both widths lie in the
+  // range in which the division by correction is used (see div_shared_fast; else the kernels divide)
+  double rdx = 1.0, rdy = 1.0;
+  int div_ok = 0;
   int row0 = 0, cx = 0, cy = 0;  // first padded mesh row of the local grid; interior cells of the mesh
   // diagonal entries 2w - 1 of the ghost rows (include/time_disc.hpp:304-337): bottom, top, and
   // left, which the right ghost column shares (:335-336); their only other entry is a 1 towards
@@ -114,6 +126,9 @@ inline void allow_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done, const
 
 // ---- launchers (all asynchronous on `st`) ---------------------------------
 int grid_for(int64_t items);
+// self-test of the division by a shared divisor (see k_selftest_division); out: two device counters
+void launch_selftest_division(hipStream_t st, double dx, double dy, uint64_t seed, int64_t count, int mode,
+                              unsigned long long *out);
 
 // part[b] = sum over block b of x[k]^2
 void launch_nrm2_part(hipStream_t st, const double *x, int64_t n, double *part, int *nparts);

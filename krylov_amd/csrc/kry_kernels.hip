@@ -501,24 +501,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil(Bands b, int64_t n, int
 // unknowns; band, centre and +-P accesses are aligned 16-byte loads.  Bands,
 // partners and the result are streamed non-temporally; x keeps the default
 // policy because its rows are reused by the neighbouring rows' sums.
-// The value itself, behind an empty asm statement: keeps a select on the result of a division a select
-// (the compiler would otherwise branch around the division).
-__device__ __forceinline__ double opaque_value(double x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
 // The five band entries of the unknown in mesh row ip, column c of an assembled implicit-Euler operator,
 // from the velocities next to it: SecondOrderCentered::Dx_m1 / Dy_m1 / Dy_p1 / Dx_p1
 // (include/space_disc.hpp:83-113) with the operations of k_offdiag for interior cells, the rows of ghost
 // cells as k_assemble leaves them (include/time_disc.hpp:304-337): the same bits as the stored bands.
-__device__ __forceinline__ void gen_band_entries(const BandGen &gen, double gdiag, int ip, int c, double um, double up,
-                                                 double vm, double vp, double (&out)[5]) {
+__device__ __forceinline__ void gen_band_entries(const BandGen &gen, const SharedDivisor &sdx, const SharedDivisor &sdy,
+                                                 double gdiag, int ip, int c, double um, double up, double vm, double vp,
+                                                 double (&out)[5]) {
   const bool xin = ip >= 1 && ip <= gen.cx, yin = c >= 1 && c <= gen.cy;
-  const double iw = opaque_value((-um / 2.0 - gen.kx) / gen.dx);
-  const double is = opaque_value((-vm / 2.0 - gen.ky) / gen.dy);
-  const double in = opaque_value((vp / 2.0 - gen.ky) / gen.dy);
-  const double ie = opaque_value((up / 2.0 - gen.kx) / gen.dx);
+  double iw, is, in, ie;
+  band_quotients(-um / 2.0 - gen.kx, -vm / 2.0 - gen.ky, vp / 2.0 - gen.ky, up / 2.0 - gen.kx, sdx, sdy, iw, is, in, ie);
   const bool inner = xin && yin;
   out[0] = inner ? iw : ((yin && ip == gen.cx + 1) ? 1.0 : 0.0);
   out[1] = inner ? is : ((xin && c == gen.cy + 1) ? 1.0 : 0.0);
@@ -542,6 +534,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
   const int64_t n2 = n >> 1;
   const int64_t P2 = P >> 1;
   const double gdiag = GEN ? *gen.cdiag : 0.0;
+  const SharedDivisor sdx = shared_divisor(gen.dx, gen.rdx, gen.div_ok != 0), sdy = shared_divisor(gen.dy, gen.rdy, gen.div_ok != 0);
   const d2 *gu2 = reinterpret_cast<const d2 *>(gen.u);
   const d2 *gv2 = reinterpret_cast<const d2 *>(gen.v);
   const d2 *x2 = reinterpret_cast<const d2 *>(x);
@@ -575,8 +568,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stencil_v2(Bands b, int64_t n, 
           const double vm1 = gen.v[k - 1], vp2 = gen.v[k + 2];
           const int row = (int)((uint32_t)k / (uint32_t)P), col0 = (int)k - row * P;
           double e0[5], e1[5];
-          gen_band_entries(gen, gdiag, gen.row0 + row, col0, um.x, up.x, vm1, vc.y, e0);
-          gen_band_entries(gen, gdiag, gen.row0 + row, col0 + 1, um.y, up.y, vc.x, vp2, e1);
+          gen_band_entries(gen, sdx, sdy, gdiag, gen.row0 + row, col0, um.x, up.x, vm1, vc.y, e0);
+          gen_band_entries(gen, sdx, sdy, gdiag, gen.row0 + row, col0 + 1, um.y, up.y, vc.x, vp2, e1);
           cw = {e0[0], e1[0]};
           cs = {e0[1], e1[1]};
           cc = {e0[2], e1[2]};
@@ -2079,6 +2072,72 @@ __global__ __launch_bounds__(64) void k_af_max_final(IeGeom g, const double *__r
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
+// Self-test of band_quotients against the division instruction sequence: `count` groups of four pseudo-random
+// numerators over the divisors dx, dy; out[0] += quotients whose bits differ from n / d, out[1] += groups that
+// took the five-operation path.  mode 0: numerators within 2^+-40 of 1, all mantissas; mode 1: every bit pattern
+// (zeros, subnormals, infinities, NaNs: the guard's side); mode 2: quotients around the limits of the guarded
+// range; mode 3: numerators whose quotient by dx is within a few units in the last place of a power of two or
+// of a midpoint between two neighbouring numbers (the hard cases of correct rounding).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t &x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void k_selftest_division(double dx, double dy, double rdx, double rdy, uint64_t seed,
+                                                               int64_t count, int mode, unsigned long long *out) {
+  const bool ok = shared_divisor_in_range(dx) && shared_divisor_in_range(dy);
+  const SharedDivisor sdx = shared_divisor(dx, rdx, ok), sdy = shared_divisor(dy, rdy, ok);
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint64_t st = seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(tid + 1));
+  unsigned long long bad = 0, fast = 0;
+  for (int64_t it = tid; it < count; it += (int64_t)gridDim.x * kBlock) {
+    double n[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t r = splitmix64(st);
+      const uint64_t frac = r & 0xFFFFFFFFFFFFFull, sign = r >> 63;
+      uint64_t e;
+      if (mode == 1) {
+        e = (r >> 52) & 0x7FF;
+      } else if (mode == 2) {
+        const int off = (int)((r >> 52) % 41) - 20;  // 2^(+-800 +- 20) times the divisor
+        const int de = (int)exponent_field((j == 0 || j == 3) ? dx : dy) - 1023;
+        int ee = 1023 + de + (((r >> 60) & 1) ? 800 : -800) + off;
+        e = (uint64_t)(ee < 0 ? 0 : (ee > 2047 ? 2047 : ee));
+      } else {
+        e = 1023 - 40 + (r >> 52) % 81;
+      }
+      n[j] = __longlong_as_double((long long)((sign << 63) | (e << 52) | frac));
+      if (mode == 3) {
+        // q0: a power of two or an arbitrary number, moved by up to four units in the last place, or by half a
+        // unit (the product with the divisor is rounded, so the quotient lands next to, not on, the hard point)
+        const double dd = (j == 0 || j == 3) ? dx : dy;
+        uint64_t qb = ((r >> 59) & 1) ? ((sign << 63) | (e << 52)) : ((sign << 63) | (e << 52) | frac);
+        qb += (uint64_t)((r >> 55) & 7) - 4;
+        const double q0 = __longlong_as_double((long long)qb);
+        const double h = ((r >> 58) & 1) ? 0.5 * (__longlong_as_double((long long)(qb + 1)) - q0) : 0.0;
+        n[j] = fma(q0, dd, h * dd);
+      }
+    }
+    double q[4];
+    if (band_quotients(n[0], n[1], n[2], n[3], sdx, sdy, q[0], q[1], q[2], q[3])) fast++;
+    const double t[4] = {n[0] / dx, n[1] / dy, n[2] / dy, n[3] / dx};
+#pragma unroll
+    for (int j = 0; j < 4; j++) bad += __double_as_longlong(q[j]) != __double_as_longlong(t[j]);
+  }
+  if (bad) atomicAdd(&out[0], bad);
+  if (fast) atomicAdd(&out[1], fast);
+}
+
+void launch_selftest_division(hipStream_t st, double dx, double dy, uint64_t seed, int64_t count, int mode,
+                              unsigned long long *out) {
+  // the reciprocals as the library forms them for a launch: one IEEE division each on the host
+  hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(kBlock), 0, st, dx, dy, 1.0 / dx, 1.0 / dy, seed, count, mode,
+                     out);
+}
+
 void launch_fill(hipStream_t st, double *x, double v, int64_t n) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, x, v, n);

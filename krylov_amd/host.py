@@ -55,6 +55,13 @@ class Context:
         check(capi.lib().kry_ctx_get_kernel_times(self.h, ms, cnt))
         return list(ms), list(cnt)
 
+    def selftest_shared_division(self, dx, dy, seed, count, mode):
+        """(quotients that differ from the device's division, groups of four served by the shortcut)."""
+        bad, fast = C.c_int64(), C.c_int64()
+        check(capi.lib().kry_selftest_shared_division(self.h, float(dx), float(dy), int(seed), int(count), int(mode),
+                                                      C.byref(bad), C.byref(fast)))
+        return bad.value, fast.value
+
     def __del__(self):
         if getattr(self, "h", None):
             capi.lib().kry_ctx_destroy(self.h)
