@@ -1325,7 +1325,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
   double *R = g->R, *cs = R + (int64_t)(m + 1) * m, *sn = cs + m, *gv = sn + m;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   g->strips = strips_usable(g, op);
-  g->cil = g->cil_capable && !fused_usable(g, op);
+  g->cil = g->cil_capable && g->ctx->nranks == 1 && !fused_usable(g, op);
   HIPCHK(hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)n, st));
   g->last_iters = 0;
   g->last_cycles = 0;
@@ -1550,7 +1550,7 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   hipStream_t st = g->ctx->stream;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   g->strips = strips_usable(g, op);
-  g->cil = g->cil_capable && !fused_usable(g, op);
+  g->cil = g->cil_capable && g->ctx->nranks == 1 && !fused_usable(g, op);
   KCHK(initial_subspace_async(g, b_dev));
   HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
   if (fused_usable(g, op)) {

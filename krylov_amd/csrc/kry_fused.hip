@@ -1225,14 +1225,14 @@ int split_from() {
   return v < 12 ? 12 : v;
 }
 
-// Last step served by the 512-thread kernel: with 47 and 48 earlier vectors it needs scratch memory and the
-// 256-thread kernel is as fast or faster (5.66 against 5.75 ms, 5.77 against 6.13 ms on an 8192 x 8192 grid).
-// Env KRY_SPLIT_UPTO overrides.
+// Last step served by the 512-thread kernel.  With 47 and 48 earlier vectors it needs scratch memory; with 47 it
+// is still the faster one (5.38 against 5.60 ms on an 8192 x 8192 grid), with 48 the 256-thread kernel is (5.66
+// against 5.77 ms).  Env KRY_SPLIT_UPTO overrides.
 int split_upto() {
   static std::atomic<int> v{-1};
   int r = v.load(std::memory_order_relaxed);
   if (r < 0) {
-    r = getenv("KRY_SPLIT_UPTO") ? atoi(getenv("KRY_SPLIT_UPTO")) : 46;
+    r = getenv("KRY_SPLIT_UPTO") ? atoi(getenv("KRY_SPLIT_UPTO")) : 47;
     v.store(r, std::memory_order_relaxed);
   }
   return r;
@@ -1266,8 +1266,8 @@ int store_tick(int nv) {
   }
   const int p = period.load(std::memory_order_relaxed);
   if (p >= 0) return nv >= from.load(std::memory_order_relaxed) ? p : 0;
-  // (41 to 46 earlier vectors: the sweeps with 16-row rings, re-measured with the interleaved basis)
-  if (nv >= 41) return nv <= 44 ? 4096 : (nv <= 46 ? 12288 : 8192);
+  // (41 to 47 earlier vectors: the sweeps with 16-row rings, re-measured with the interleaved basis)
+  if (nv >= 41) return nv <= 44 ? 4096 : (nv <= 47 ? 12288 : 8192);
   return nv <= 3 ? 0 : (nv <= 7 ? 2048 : (nv <= 12 ? 3072 : (nv <= 18 ? 4096 : (nv <= 27 ? 6144 : 8192))));
 }
 // Register sets of the 256-thread kernel for step nv (its requests run sets - 1 rows ahead).  Sweeps over few
