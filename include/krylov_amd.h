@@ -230,13 +230,15 @@ int kry_gmres_get_one_sweep(const kry_gmres *g);
  * else 0.  Environment KRY_STRIP_MAJOR=0 switches it off. */
 int kry_gmres_basis_strip_major(const kry_gmres *g);
 /* The other storage without a counterpart in the reference: a solve on one rank whose every step runs the
- * Gram-Schmidt chain (line preconditioner, num_iters above the one-sweep range, CSR operators) keeps its
+ * Gram-Schmidt chain (line preconditioner, num_iters above the one-sweep range, CSR operators) may keep its
  * basis chunk-interleaved -- 512 values of vector 0, the same 512 of vector 1, ... -- so that the chain's
  * kernels, which read up to 64 vectors per pass, stream one contiguous piece per chunk instead of 64 pieces
- * in 64 different memory pages.  Same bits; kry_gmres_subspace_vector returns contiguous vectors, and the
- * step-wise interface (initial_subspace / add_arnoldi) works on contiguous vectors.  Returns 1 if the basis
- * of the last solve was stored that way.  Environment KRY_CHAIN_INTERLEAVE=0 (read when a solver is
- * created) switches it off. */
+ * in 64 different memory pages.  It does where that pays: from num_iters 32 on, and for the line
+ * preconditioner on meshes where the preconditioner kernel also normalises its operand (the copy of the
+ * newest vector that the layout otherwise costs then falls away).  Same bits; kry_gmres_subspace_vector
+ * returns contiguous vectors, and the step-wise interface (initial_subspace / add_arnoldi) works on
+ * contiguous vectors.  Returns 1 if the basis of the last solve was stored that way.  Environment
+ * KRY_CHAIN_INTERLEAVE (read when a solver is created): 0 never, 2 wherever possible. */
 int kry_gmres_basis_chunk_interleaved(const kry_gmres *g);
 /* How the last Arnoldi step of a cycle obtains H(m, m-1) = ||w - sum_k h_k v_k||, the normalisation
  * at the end of gram_schmidt (include/solver.hpp:209); no counterpart in the reference, which

@@ -279,6 +279,7 @@ struct kry_gmres {
   // step of the Gram-Schmidt chain.  The newest vector is then kept contiguous as well, in v0, for the kernels
   // that take it as their operand (operator, line preconditioner).
   bool cil_capable = false, cil = false;
+  bool cil_always = false;  // environment KRY_CHAIN_INTERLEAVE=2 when the solver is created: wherever possible
   // Between two chain steps of a fixed cycle with the line preconditioner: w holds the next basis vector
   // un-normalised and pend_part the partial sums of its squares; the preconditioner kernel of the next step
   // normalises it on the way in (k_tdp_apply2 with SC) instead of a pass of its own.
@@ -923,6 +924,7 @@ static int gmres_create(kry_ctx *ctx, int64_t n, int m, int flags, int64_t halo_
   if (ctx->nranks == 1 && !(getenv("KRY_CHAIN_INTERLEAVE") && atoi(getenv("KRY_CHAIN_INTERLEAVE")) == 0)) {
     // whole chunks, so that the m + 1 vectors fit the same array chunk-interleaved
     g->cil_capable = true;
+    g->cil_always = getenv("KRY_CHAIN_INTERLEAVE") && atoi(getenv("KRY_CHAIN_INTERLEAVE")) == 2;
     g->ld = g->halo + (n + kChunk - 1) / kChunk * kChunk + g->halo;
   }
   if (getenv("KRY_TDP_FUSE_SCALE") && atoi(getenv("KRY_TDP_FUSE_SCALE")) == 0) g->fuse_scale = false;  // experimentation knob
@@ -1231,6 +1233,17 @@ static bool tdp_fuses_scale(const kry_gmres *g) {
          tdp_scaled_supported(g->lo, g->dd, g->ud, g->w, g->z, g->V + g->halo, g->nlines, g->L);
 }
 
+// Whether a solve with this operator keeps its basis chunk-interleaved: every step runs the chain on one rank,
+// and the layout pays -- a kernel of the chain reads more vectors than a compute unit's translation caches
+// cover (from 32 steps per cycle on), or the copy of the newest vector that the layout otherwise needs falls
+// away because the preconditioner kernel normalises it on the way in.  (GMRES(30) on a CSR matrix, 8192^2:
+// 153.5 ms per cycle with contiguous vectors, 156.4 interleaved.)
+static bool fused_usable(const kry_gmres *g, const kry_op *op);
+static bool chain_interleaved(const kry_gmres *g, const kry_op *op) {
+  if (!g->cil_capable || g->ctx->nranks != 1 || fused_usable(g, op)) return false;
+  return g->cil_always || g->m >= 32 || tdp_fuses_scale(g);
+}
+
 // another_follows: the caller queues the next chain step of the same cycle right behind this one (the
 // normalisation of this step's vector may then be left to that step's preconditioner kernel).
 static int arnoldi_async(kry_gmres *g, kry_op *op, bool another_follows = false) {
@@ -1325,7 +1338,7 @@ static int solve_extended(kry_gmres *g, kry_op *op, const double *b_dev, double 
   double *R = g->R, *cs = R + (int64_t)(m + 1) * m, *sn = cs + m, *gv = sn + m;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   g->strips = strips_usable(g, op);
-  g->cil = g->cil_capable && g->ctx->nranks == 1 && !fused_usable(g, op);
+  g->cil = chain_interleaved(g, op);
   HIPCHK(hipMemsetAsync(g->vars, 0, sizeof(double) * (size_t)n, st));
   g->last_iters = 0;
   g->last_cycles = 0;
@@ -1550,7 +1563,7 @@ static int solve_async(kry_gmres *g, kry_op *op, const double *b_dev, double *x_
   hipStream_t st = g->ctx->stream;
   if (g->flags & KRY_GMRES_TDP) KCHK(tdp_setup_async(g, op));
   g->strips = strips_usable(g, op);
-  g->cil = g->cil_capable && g->ctx->nranks == 1 && !fused_usable(g, op);
+  g->cil = chain_interleaved(g, op);
   KCHK(initial_subspace_async(g, b_dev));
   HIPCHK(hipMemsetAsync(g->H, 0, sizeof(double) * (size_t)(g->m + 1) * g->m, st));
   if (fused_usable(g, op)) {

@@ -4,10 +4,12 @@ The reference keeps its Krylov basis as a std::vector of vectors
 (include/solver.hpp:236).  On one rank, a solve whose every Arnoldi step runs
 the Gram-Schmidt chain (the line preconditioner of GMRESTDPSolver,
 include/solver.hpp:254-331, more steps than the one-sweep kernels serve, CSR
-operators) stores the vectors 512 values at a time, interleaved.  Only
-addresses change: every value is produced by the same lane with the same
+operators) may store the vectors 512 values at a time, interleaved; it does so
+where that pays (from 32 steps per cycle on, or where the preconditioner kernel
+also normalises its operand), and with KRY_CHAIN_INTERLEAVE=2 wherever it can.
+Only addresses change: every value is produced by the same lane with the same
 operations in the same order, so everything must have the same bits as with
-KRY_CHAIN_INTERLEAVE=0 (read when a solver is created).
+KRY_CHAIN_INTERLEAVE=0 (both read when a solver is created).
 """
 import os
 
@@ -41,8 +43,13 @@ def contiguous_basis():
     return environment("KRY_CHAIN_INTERLEAVE")
 
 
+def interleaved_basis():
+    return environment("KRY_CHAIN_INTERLEAVE", "2")
+
+
 def pair(ctx, **kw):
-    a = host.ImplicitEuler(ctx, **kw)
+    with interleaved_basis():
+        a = host.ImplicitEuler(ctx, **kw)
     with contiguous_basis():
         b = host.ImplicitEuler(ctx, **kw)
     return a, b
@@ -96,7 +103,7 @@ def test_normalisation_inside_the_preconditioner_kernel_has_the_same_bits(ctx, s
     the interleaved basis."""
     prob = problems.s_aniso(*shape)
     a = host.ImplicitEuler(ctx, **prob, m=m, tdp=True, **kw)
-    with environment("KRY_TDP_FUSE_SCALE"):
+    with environment("KRY_TDP_FUSE_SCALE"), interleaved_basis():
         b = host.ImplicitEuler(ctx, **prob, m=m, tdp=True, **kw)
         with contiguous_basis():
             c = host.ImplicitEuler(ctx, **prob, m=m, tdp=True, **kw)
@@ -112,6 +119,10 @@ def test_normalisation_inside_the_preconditioner_kernel_has_the_same_bits(ctx, s
         va = a.solver().subspace_vector(k)
         for x in (b, c, d):
             assert np.array_equal(va, x.solver().subspace_vector(k), equal_nan=True)
+    # interleaved by default where the preconditioner kernel normalises, or from 32 steps per cycle on
+    assert a.solver().basis_chunk_interleaved() == (fused or m >= 32)
+    assert b.solver().basis_chunk_interleaved()
+    assert not c.solver().basis_chunk_interleaved() and not d.solver().basis_chunk_interleaved()
     # launches of the normalisation per cycle: ||b||, v_0, and one per step unless the preconditioner kernel does it
     normalize = capi.K_NAMES.index("normalize")
     for x, f in ((a, fused), (b, False), (c, False), (d, fused)):
@@ -135,7 +146,8 @@ def test_stand_alone_solver_with_a_csr_operator(ctx, n, m, tdp):
     A.sort_indices()
     b = rng.standard_normal(n)
     op = host.Operator.csr(ctx, A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data)
-    ga = host.GMRESSolver(ctx, n, m, tdp=tdp)
+    with interleaved_basis():
+        ga = host.GMRESSolver(ctx, n, m, tdp=tdp)
     with contiguous_basis():
         gb = host.GMRESSolver(ctx, n, m, tdp=tdp)
     xa, xb = ga.solve(op, b), gb.solve(op, b)
@@ -157,3 +169,7 @@ def test_stand_alone_solver_with_a_csr_operator(ctx, n, m, tdp):
     # and a solve after that is interleaved again
     assert np.array_equal(ga.solve(op, b), xb, equal_nan=True)
     assert ga.basis_chunk_interleaved()
+    # the default: from 32 steps per cycle on
+    gd = host.GMRESSolver(ctx, n, m, tdp=tdp)
+    assert np.array_equal(gd.solve(op, b), xb, equal_nan=True)
+    assert gd.basis_chunk_interleaved() == (m >= 32)

@@ -21,7 +21,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/r03x/cfg5 -o run -- python3 $ROOT/bench.py --problem s_aniso --tdp --fixed-precond --steps 2 --warmup 1 --no-cpu-baseline > $ROOT/gpurun_out/r03x/bench_cfg5_under_rocprof.json 2> $ROOT/gpurun_out/r03x/cfg5.err || { echo "cfg5 stats failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/r03x/cfg2 -o run -- python3 $ROOT/bench.py --mesh 2048 --gmres-m 30 --steps 100 --warmup 3 --no-cpu-baseline > $ROOT/gpurun_out/r03x/bench_cfg2_under_rocprof.json 2> $ROOT/gpurun_out/r03x/cfg2.err || { echo "cfg2 stats failed"; exit 1; }
 cd $ROOT
-timeout -k 10 120 python3 bench.py --extended 1e-4 --gmres-m 10 --problem s_aniso --tdp --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03x/bench_extended_s_aniso_tdp10_rtol1e-4.json 2> gpurun_out/r03x/ext_aniso.err
 bash tools/sweep_mem_counters.sh > gpurun_out/r03x/sweep_mem_table.txt 2> gpurun_out/r03x/sweep_mem.err || echo "mem counters failed"
 bash tools/sweep_sq_counters.sh > gpurun_out/r03x/sweep_sq_table.txt 2> gpurun_out/r03x/sweep_sq.err || echo "sq counters failed"
 bash tools/sweep_sq_counters2.sh > gpurun_out/r03x/sweep_sq2_table.txt 2> gpurun_out/r03x/sweep_sq2.err || echo "sq counters 2 failed"
