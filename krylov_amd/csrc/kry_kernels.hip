@@ -2198,7 +2198,10 @@ static void launch_spmv_stencil_t(hipStream_t st, const Bands &b, int64_t n, int
   int g = grid_for(n);
   if (vec) {
     const int64_t tiles = ((n >> 1) + (int64_t)kBlock * U - 1) / ((int64_t)kBlock * U);
-    g = (int)(tiles < 256 ? tiles : 256);
+    // (experimentation knob KRY_SPMV_GRID; with 32 partner vectors and generated bands on an 8192 x 8192 grid:
+    // 128 workgroups 4.51 ms, 256 3.50, 512 3.53, 768 3.57, 1024 3.54; one element per lane instead of two: 3.49)
+    static const int cap = getenv("KRY_SPMV_GRID") ? atoi(getenv("KRY_SPMV_GRID")) : 256;
+    g = (int)(tiles < cap ? tiles : cap);
   }
   if (nparts) *nparts = g;
   if (vec && gen != nullptr)
