@@ -188,6 +188,39 @@ def test_config2_2048_gmres30_one_step_vs_cpu(ctx, jobs, capfd):
     yardstick(capfd, "config 2: 2048^2, GMRES(30)", dev, ref, exact)
 
 
+def test_config2_through_the_general_operator_vs_cpu(ctx, jobs, capfd):
+    """The same system handed over as a general matrix (`solve(Matrix, Vector)`, src/bindpy.cpp:669-707): the
+    assembled operator of the 2048^2 mesh as CSR (21 million entries), a stand-alone GMRESSolver<30>, against the
+    CPU run of config 2 -- the CSR operator kernel and the Gram-Schmidt chain at a size where many workgroups,
+    partial sums and chunks exist."""
+    import bench
+    dev = host.ImplicitEuler(ctx, **problems.s_iso(2048), m=0, bc_time_dependent=False)
+    dev.assemble_system(DT)
+    rowptr, col, val = bench.csr_from_bands(dev.bands())
+    op = host.Operator.csr(ctx, rowptr, col, val)
+    b = dev.expand(dev.sol_vec())
+    ref, _ = jobs.result("cfg2", capfd)
+    for label, env in (("contiguous basis", "0"), ("chunk-interleaved basis", "2")):
+        old = os.environ.get("KRY_CHAIN_INTERLEAVE")
+        os.environ["KRY_CHAIN_INTERLEAVE"] = env
+        try:
+            g = host.GMRESSolver(ctx, b.shape[0], 30)
+        finally:
+            if old is None:
+                del os.environ["KRY_CHAIN_INTERLEAVE"]
+            else:
+                os.environ["KRY_CHAIN_INTERLEAVE"] = old
+        x = dev.compact(g.solve(op, b))
+        assert g.basis_chunk_interleaved() == (env == "2")
+        H = g.hessenberg_matrix()
+        err = rel(x, ref["delta"])
+        hcols = np.max(np.abs(H - ref["H"]), axis=0) / np.max(np.abs(ref["H"]))
+        say(capfd, "[config 2 as a CSR matrix, stand-alone GMRES(30), %s] rel. error of the solution vs CPU %.2e, H worst "
+            "column %.2e (column %d)" % (label, err, float(np.max(hcols)), int(np.argmax(hcols))))
+        assert err <= RTOL
+        assert float(np.max(hcols[:6])) <= RTOL
+
+
 def test_config3_8192_gmres50_one_step_vs_cpu(ctx, jobs, capfd):
     """BASELINE config 3 at full size on one GPU, default path: the headline
     workload of bench.py against the CPU restatement."""
