@@ -1229,7 +1229,10 @@ static int initial_subspace_async(kry_gmres *g, const double *b_dev) {
 // Whether the chain steps of a fixed cycle leave the normalisation of their vector to the next step's
 // preconditioner kernel
 static bool tdp_fuses_scale(const kry_gmres *g) {
-  return g->fuse_scale && (g->flags & KRY_GMRES_TDP) && !(g->flags & KRY_GMRES_EXTENDED) && g->tdp_ready && g->nlines * g->L == g->n &&
+  // (one rank: on several the norm arrives as an all-reduced total, a combination no test on a mesh of the size the
+  // 16-byte-lane kernel needs covers)
+  return g->fuse_scale && g->ctx->nranks == 1 && (g->flags & KRY_GMRES_TDP) && !(g->flags & KRY_GMRES_EXTENDED) &&
+         g->tdp_ready && g->nlines * g->L == g->n &&
          tdp_scaled_supported(g->lo, g->dd, g->ud, g->w, g->z, g->V + g->halo, g->nlines, g->L);
 }
 
